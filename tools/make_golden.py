@@ -1,0 +1,297 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the reference (HSG-AIML/MaskedSST) in THIS container.
+
+The reference Python cannot travel to the GPU box, so its outputs are captured here as small
+``.npz`` fixtures under ``tests/golden/`` and committed together with this script.
+
+Protocol: ``random.seed(5); np.random.seed(5); torch.manual_seed(5)``; build the
+reference encoder, wrap it in the reference SimMIM module, ``x = torch.randn(B, C, 8, 8)``,
+``eval()`` (dropout off), forward -> loss, backward -> grads.  For every case we store
+
+* the config, the bool mask (bit-packed) and the masked indices (bit-exact parity targets),
+* per-tensor fingerprints of every parameter and every gradient
+  (float64 sum, float64 abs-sum, first 8 elements) -- the oracle re-draws the parameters from the
+  same seed in the same order, so a fingerprint is enough to pin it,
+* fingerprints of the intermediates (tokens after embed / after mask scatter / after the spatial
+  stack / after the spectral stack / predicted pixels) and the loss,
+* for the ``tiny`` case the FULL state_dict, input and gradients (element-wise checks).
+
+Also captured: an AdamW loss trajectory on the BASELINE config-1 shape (5 steps, clamp hook,
+dropout 0) and a finetune (classification) step.
+
+Run:  PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py
+"""
+import os
+import sys
+import random
+import json
+
+import numpy as np
+
+np.float = float  # reference src/pos_embed.py:52 uses the alias removed in numpy>=1.24
+
+import torch
+import torch.nn.functional as F
+
+REF = os.environ.get("MSST_REFERENCE", "/root/reference")
+sys.path.insert(0, REF)
+sys.dont_write_bytecode = True
+
+from src.vit_spatial_spectral import ViTSpatialSpectral  # noqa: E402
+from src.vit_simmim_original import SimMIMSpatialSpectral  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+SEED = 5
+
+
+def seed_all():
+    random.seed(SEED)
+    np.random.seed(SEED)
+    torch.manual_seed(SEED)
+
+
+def fp(t):
+    """fingerprint: [sum, abs-sum] in float64 + first 8 elements + shape."""
+    t = t.detach().to(torch.float64).reshape(-1)
+    head = np.zeros(8, dtype=np.float64)
+    n = min(8, t.numel())
+    head[:n] = t[:n].numpy()
+    return np.concatenate([[t.sum().item(), t.abs().sum().item(), float(t.numel())], head])
+
+
+def build(cfg):
+    enc = ViTSpatialSpectral(
+        image_size=8,
+        spatial_patch_size=1,
+        spectral_patch_size=10,
+        num_classes=cfg.get("n_classes", 8),
+        dim=96,
+        depth=cfg["depth"],
+        heads=cfg.get("heads", 8),
+        mlp_dim=64,
+        dropout=cfg.get("dropout", 0.0),
+        emb_dropout=cfg.get("dropout", 0.0),
+        channels=cfg["bands"],
+        spectral_pos_embed=cfg.get("spectral_pos_embed", False),
+        spectral_pos=torch.arange(cfg["bands"] // 10),
+        blockwise_patch_embed=True,
+        spectral_only=False,
+    )
+    model = SimMIMSpatialSpectral(
+        encoder=enc,
+        intermediate_losses=False,
+        masking_ratio=cfg.get("masking_ratio", 0.7),
+        mask_patch_size=cfg.get("mask_patch_size", 4),
+        to_pixels_per_spectral_block=cfg.get("to_pixels_per_spectral_block", True),
+        tube_masking=cfg.get("tube_masking", True),
+    )
+    return model
+
+
+def staged_forward(model, x):
+    """Re-run the reference forward stage by stage using the reference's own sub-modules
+    (same RNG draws as SimMIMSpatialSpectral.forward) to expose intermediates."""
+    enc = model.encoder
+    patches = model.to_patch(x)
+    B = patches.shape[0]
+    tokens = model.patch_to_emb(patches)
+    patches = patches.reshape(B, -1, patches.shape[-1])
+    T = tokens.shape[1]
+    if enc.spectral_pos_embed:
+        pos = enc.get_pos_embeddings()
+    else:
+        pos = enc.pos_embedding[:, :T]
+    tok_embed = tokens
+    tokens = tokens + pos
+    mask_tokens = model.mask_token[None, None, :] + pos
+    num_masked = int(model.masking_ratio * T)
+    if model.mask_patch_size == 1:
+        idx = torch.rand(B, T).topk(k=num_masked, dim=-1).indices
+        bm = torch.zeros((B, T)).scatter_(-1, idx, 1).bool()
+    elif model.tube_masking:
+        bm, idx = model.mask_generator.get_batch_tube_masked(
+            batch_size=B, channel_tokens=enc.num_spectral_patches, num_masked=num_masked, device=x.device
+        )
+    else:
+        bm, idx = model.mask_generator.get_batch(
+            batch_size=B, channel_tokens=enc.num_spectral_patches, num_masked=num_masked, device=x.device
+        )
+    tok_masked = torch.where(bm[..., None], mask_tokens, tokens)
+    seq = enc.spatial_spectral_transformer
+    t0 = seq[0](tok_masked)
+    t1 = seq[1](t0)  # spatial stack
+    t2 = seq[2](t1)
+    t3 = seq[3](t2)  # spectral stack
+    enc_out = seq[4](t3)
+    after_spatial = t1.reshape(B, enc.num_spectral_patches, enc.num_spatial_patches, -1).reshape(B, T, -1)
+    br = torch.arange(B)[:, None]
+    enc_m = enc_out[br, idx]
+    if model.to_pixels_per_spectral_block:
+        blk = torch.arange(enc.num_spectral_patches).repeat_interleave(enc.num_spatial_patches)
+        blk = blk.unsqueeze(0).repeat(B, 1)[br, idx]
+        pred = model.to_pixels(enc_m, blk)
+    else:
+        pred = model.to_pixels(enc_m)
+    target = patches[br, idx]
+    loss = F.l1_loss(pred, target) / num_masked
+    return dict(
+        tok_embed=tok_embed, tok_masked=tok_masked, after_spatial=after_spatial, enc_out=enc_out,
+        pred=pred, target=target, loss=loss, bool_mask=bm, masked_indices=idx,
+    )
+
+
+def run_case(name, cfg, full=False):
+    seed_all()
+    model = build(cfg)
+    B, C = cfg["B"], cfg["bands"]
+    x = torch.randn(B, C, 8, 8)
+    if cfg.get("zero_pad_bands"):
+        x[:, C - cfg["zero_pad_bands"]:] = 0.0
+    model.eval()
+
+    np_state = np.random.get_state()
+    t_state = torch.get_rng_state()
+    loss = model(x)
+    model.zero_grad()
+    loss.backward()
+    grads = {k: p.grad for k, p in model.named_parameters()}
+
+    # staged re-run with the same RNG state
+    np.random.set_state(np_state)
+    torch.set_rng_state(t_state)
+    with torch.no_grad():
+        st = staged_forward(model, x)
+    assert torch.equal(st["loss"], loss.detach()), (st["loss"].item(), loss.item())
+
+    out = {
+        "cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+        "loss": np.array(loss.item(), dtype=np.float64),
+        "loss_f32": loss.detach().numpy(),
+        "x_fp": fp(x),
+        "bool_mask_bits": np.packbits(st["bool_mask"].numpy().astype(np.uint8), axis=-1),
+        "masked_indices": st["masked_indices"].numpy().astype(np.int16),
+        "n_params": np.array(sum(p.numel() for p in model.parameters()), dtype=np.int64),
+    }
+    gsq = 0.0
+    names = []
+    for k, p in model.named_parameters():
+        names.append(k)
+        out["p_fp/" + k] = fp(p)
+        g = grads[k]
+        if g is None:
+            out["g_none/" + k] = np.array(1)
+        else:
+            out["g_fp/" + k] = fp(g)
+            gsq += float((g.double() ** 2).sum())
+    out["names"] = np.frombuffer("\n".join(names).encode(), dtype=np.uint8)
+    out["grad_l2"] = np.array(gsq ** 0.5, dtype=np.float64)
+    for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred", "target"]:
+        out["i_fp/" + k] = fp(st[k])
+        # a deterministic 64-element strided slice for element-wise checks
+        flat = st[k].reshape(-1)
+        stride = max(1, flat.numel() // 64)
+        out["i_slice/" + k] = flat[::stride][:64].numpy().astype(np.float32)
+    if full:
+        out["x"] = x.numpy()
+        for k, v in model.state_dict().items():
+            out["sd/" + k] = v.numpy()
+        for k, g in grads.items():
+            if g is not None:
+                out["grad/" + k] = g.numpy()
+        for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred", "target"]:
+            out["full/" + k] = st[k].numpy()
+    np.savez_compressed(os.path.join(OUT, f"simmim_{name}.npz"), **out)
+    print(f"{name}: loss={loss.item():.9e} grad_l2={gsq ** 0.5:.6e} n_params={int(out['n_params'])} "
+          f"idx[1,:4]={st['masked_indices'][min(1, B - 1), :4].tolist()}")
+
+
+def run_adamw_traj():
+    """BASELINE config 1 plumbing case: depth 2, 32 cubes 8x8x200, AdamW lr 0.008 wd 0.05,
+    clamp hook (pretrain.py:71-73), dropout 0 (deterministic), 5 steps."""
+    cfg = dict(bands=200, depth=2, B=32, dropout=0.0)
+    seed_all()
+    model = build(cfg)
+    x = torch.randn(32, 200, 8, 8)
+    opt = torch.optim.AdamW(model.parameters(), lr=0.008, weight_decay=0.05)
+    for p in model.parameters():
+        p.register_hook(lambda grad: torch.clamp(grad, -1, 1))
+    model.train()
+    losses = []
+    for _ in range(5):
+        opt.zero_grad()
+        loss = model(x)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    out = {
+        "cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+        "losses": np.array(losses, dtype=np.float64),
+        "lr": np.array(0.008), "weight_decay": np.array(0.05),
+    }
+    for k, p in model.named_parameters():
+        out["p_fp_after/" + k] = fp(p)
+    np.savez_compressed(os.path.join(OUT, "adamw_traj_200b_L2_B32.npz"), **out)
+    print("adamw traj:", losses)
+
+
+def run_finetune_case(name, cfg):
+    """Classification step (finetune.py / src/utils.py:608-663): logits [B,ncls,8,8], CE(ignore -1)."""
+    seed_all()
+    enc = ViTSpatialSpectral(
+        image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=cfg["n_classes"],
+        dim=96, depth=cfg["depth"], heads=8, mlp_dim=64, dropout=0.0, emb_dropout=0.0,
+        channels=cfg["bands"], spectral_pos_embed=cfg["spectral_pos_embed"],
+        spectral_pos=torch.arange(cfg["bands"] // 10), blockwise_patch_embed=True,
+    )
+    B = cfg["B"]
+    x = torch.randn(B, cfg["bands"], 8, 8)
+    label = torch.randint(-1, cfg["n_classes"], (B, 8, 8))
+    enc.eval()
+    logits = enc(x)
+    loss = F.cross_entropy(logits, label, ignore_index=-1)
+    loss.backward()
+    out = {
+        "cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+        "loss": np.array(loss.item(), dtype=np.float64),
+        "label": label.numpy().astype(np.int8),
+        "logits_fp": fp(logits),
+        "logits": logits.detach().numpy() if logits.numel() <= 8192 else logits.detach().numpy()[:4],
+        "n_params": np.array(sum(p.numel() for p in enc.parameters()), dtype=np.int64),
+    }
+    gsq = 0.0
+    names = []
+    for k, p in enc.named_parameters():
+        names.append(k)
+        out["p_fp/" + k] = fp(p)
+        out["g_fp/" + k] = fp(p.grad)
+        gsq += float((p.grad.double() ** 2).sum())
+    out["names"] = np.frombuffer("\n".join(names).encode(), dtype=np.uint8)
+    out["grad_l2"] = np.array(gsq ** 0.5, dtype=np.float64)
+    np.savez_compressed(os.path.join(OUT, f"finetune_{name}.npz"), **out)
+    print(f"finetune {name}: loss={loss.item():.9e} grad_l2={gsq ** 0.5:.6e} n_params={int(out['n_params'])}")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "tiny":  # regenerate only the element-wise cases
+        run_case("tiny_20b_L1_B2_h2", dict(bands=20, depth=1, B=2, heads=2), full=True)
+        run_case("tiny_30b_L1_B3_h2_nontube", dict(bands=30, depth=1, B=3, heads=2, tube_masking=False), full=True)
+        sys.exit(0)
+    # element-wise case: everything stored in full
+    run_case("tiny_20b_L1_B2_h2", dict(bands=20, depth=1, B=2, heads=2), full=True)
+    run_case("tiny_30b_L1_B3_h2_nontube", dict(bands=30, depth=1, B=3, heads=2, tube_masking=False), full=True)
+    # BASELINE shapes (fingerprints only)
+    run_case("200b_L2_B32", dict(bands=200, depth=2, B=32))
+    run_case("50b_L12_B8", dict(bands=50, depth=12, B=8))
+    run_case("50b_L12_B8_zeropad", dict(bands=50, depth=12, B=8, zero_pad_bands=2))
+    run_case("200b_L12_B4", dict(bands=200, depth=12, B=4))
+    # option coverage
+    run_case("50b_L2_B4_mps1", dict(bands=50, depth=2, B=4, mask_patch_size=1))
+    run_case("50b_L2_B4_nontube", dict(bands=50, depth=2, B=4, tube_masking=False))
+    run_case("50b_L2_B4_specpos", dict(bands=50, depth=2, B=4, spectral_pos_embed=True))
+    run_case("50b_L2_B4_sharedpix", dict(bands=50, depth=2, B=4, to_pixels_per_spectral_block=False))
+    run_case("50b_L2_B4_mps2_r50", dict(bands=50, depth=2, B=4, mask_patch_size=2, masking_ratio=0.5))
+    run_adamw_traj()
+    run_finetune_case("200b_L4_B2", dict(bands=200, depth=4, B=2, n_classes=8, spectral_pos_embed=False))
+    run_finetune_case("50b_L2_B2_specpos", dict(bands=50, depth=2, B=2, n_classes=20, spectral_pos_embed=True))
