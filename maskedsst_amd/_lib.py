@@ -1,0 +1,90 @@
+"""ctypes binding of libmsst.so (the C-ABI declared in include/msst.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.  Build the
+library with ``python -m maskedsst_amd.build`` (hipcc, gfx950).
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_long, c_float, c_void_p, c_char_p, POINTER, Structure
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmsst.so")
+
+PREC_F32 = 0
+PREC_BF16 = 1
+MODE_SPATIAL = 0
+MODE_SPECTRAL = 1
+MLP_SLAB = 64 * 96 + 96 * 64 + 64 + 96 + 96 + 96
+ATTN_SLAB = 3 * 64 * 96 + 96 * 64
+
+
+class MsstError(RuntimeError):
+    pass
+
+
+class MsstPrepJob(Structure):
+    _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int32), ("cols", c_int32),
+                ("transpose", c_int32), ("_pad", c_int32)]
+
+
+class MsstBlockWeights(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "wqkv", "wout", "w1", "w2", "wqkvT", "woutT", "w1T", "w2T",
+        "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2")]
+
+
+_P = c_void_p
+_SIGS = {
+    "msst_version": (c_int, []),
+    "msst_last_error": (c_char_p, []),
+    "msst_prep_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
+    "msst_tokenize_fwd": (c_int, [_P] * 9 + [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, _P]),
+    "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                              c_int, _P]),
+    "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, c_int, c_int, c_int, c_int,
+                              c_int, c_int, _P]),
+    "msst_block_bwd_mlp": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                   c_int, c_int, _P]),
+    "msst_block_bwd_attn": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_int, _P]),
+    "msst_block_bwd_ln1": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, _P, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, _P]),
+    "msst_reduce_slabs": (c_int, [_P, c_int, c_long, _P, c_int, c_int, _P]),
+    "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_int, c_int, _P]),
+    "msst_adamw": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
+                           c_float, c_float, _P]),
+}
+
+_lib = None
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def load():
+    """Load libmsst.so (once).  Raises MsstError when it is absent -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MsstError(
+            f"{LIB_PATH} not found: build the HIP extension first (python -m maskedsst_amd.build). "
+            "maskedsst_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise MsstError(f"libmsst.so does not export {name} (stale build? run python -m maskedsst_amd.build)")
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().msst_last_error()
+        raise MsstError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")

@@ -1,0 +1,174 @@
+// Device-side primitives shared by the MaskedSST gfx950 kernels.
+//
+// Two precision policies drive one set of kernel templates:
+//   PF32  -- exact fp32 operands on v_mfma_f32_16x16x4_f32   (parity mode, 1e-4 vs the CPU oracle)
+//   PBF16 -- bf16 operands on v_mfma_f32_16x16x32_bf16, fp32 accumulate (throughput mode)
+// Both instructions share the C/D fragment layout (col = lane&15, row = 4*(lane>>4)+reg), so all
+// epilogues (softmax, LayerNorm, GELU, residuals) are written once.
+//
+// GEMM convention used everywhere ("NT"): C[i][j] += sum_k A[i][k] * B[j][k].
+//   A fragment: lane holds A[i0 + (lane&15)][k-slice (lane>>4)]
+//   B fragment: lane holds B[j0 + (lane&15)][k-slice (lane>>4)]
+//   C fragment: lane holds C[i0 + 4*(lane>>4) + r][j0 + (lane&15)], r = 0..3
+// so the cheap ("natural") store of a C tile is OUT[j][i..i+3]: 4 consecutive i for one j.
+// Weights are normally the A operand and activations the B operand, which makes activation
+// outputs row-major [token][feature] with 16-byte stores.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace msst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t bf16_t;
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    // round-to-nearest-even; NaN stays NaN
+    uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
+    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) r = u | 0x00400000u;
+    return (bf16_t)(r >> 16);
+}
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ------------------------------------------------------------------------------------------
+// precision policies
+// ------------------------------------------------------------------------------------------
+struct PF32 {
+    typedef float elem;
+    typedef float frag;
+    static constexpr int KS = 4;    // k per MFMA
+    static constexpr int UNROLL = 2;          // k-loop unroll (24 / 16 steps per GEMM)
+    static constexpr int WAVES_PER_SIMD = 1;  // launch-bounds occupancy target (LDS allows 1 WG/CU)
+    static constexpr int PADE = 4;  // LDS row padding in elements (16 bytes)
+    static __device__ __forceinline__ elem cvt(float f) { return f; }
+    static __device__ __forceinline__ float up(elem e) { return e; }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+    // k-contiguous operand: element (row, k) at p[row*ld + k]
+    static __device__ __forceinline__ frag ld_kc(const elem* p, int ld) {
+        const int l = lane_id();
+        return p[(l & 15) * ld + (l >> 4)];
+    }
+    // k-strided operand: element (row, k) at p[k*ld + row]
+    static __device__ __forceinline__ frag ld_ks(const elem* p, int ld) {
+        const int l = lane_id();
+        return p[(l >> 4) * ld + (l & 15)];
+    }
+    // natural store of a C tile: OUT[j][i0..i0+3], p -> OUT[j0][i0]
+    static __device__ __forceinline__ void st_nat(elem* p, int ld, f32x4 c) {
+        const int l = lane_id();
+        *reinterpret_cast<f32x4*>(p + (l & 15) * ld + 4 * (l >> 4)) = c;
+    }
+    // transposed store: OUT[i][j], p -> OUT[i0][j0]
+    static __device__ __forceinline__ void st_tr(elem* p, int ld, f32x4 c) {
+        const int l = lane_id();
+        elem* q = p + (4 * (l >> 4)) * ld + (l & 15);
+        q[0] = c[0]; q[ld] = c[1]; q[2 * ld] = c[2]; q[3 * ld] = c[3];
+    }
+};
+
+struct PBF16 {
+    typedef bf16_t elem;
+    typedef s16x8 frag;
+    static constexpr int KS = 32;
+    static constexpr int UNROLL = 3;
+    static constexpr int WAVES_PER_SIMD = 2;
+    static constexpr int PADE = 8;  // 16 bytes
+    static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
+    static __device__ __forceinline__ float up(elem e) { return bf2f(e); }
+    static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
+            __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, b), c, 0, 0, 0);
+    }
+    static __device__ __forceinline__ frag ld_kc(const elem* p, int ld) {
+        const int l = lane_id();
+        return *reinterpret_cast<const s16x8*>(p + (l & 15) * ld + 8 * (l >> 4));
+    }
+    // k-strided operand in LDS: element (row, k) at p[k*ld + row].  Two ds_read_b64_tr_b16: the 16
+    // lanes of a group fetch a [4 k][16 row] block (lane i supplies the address of k-row i>>2,
+    // column chunk (i&3)*4) and each receives column i = its 4 consecutive-k values
+    // (semantics probed on gfx950 with tools/probe_tr.hip).  ld must be a multiple of 4.
+    static __device__ __forceinline__ frag ld_ks(const elem* p, int ld) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int l = lane_id();
+        const elem* q = p + (8 * (l >> 4) + ((l & 15) >> 2)) * ld + (l & 3) * 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 4 * ld));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    static __device__ __forceinline__ void st_nat(elem* p, int ld, f32x4 c) {
+        const int l = lane_id();
+        s16x4 v;
+        v[0] = (short)f2bf(c[0]); v[1] = (short)f2bf(c[1]); v[2] = (short)f2bf(c[2]); v[3] = (short)f2bf(c[3]);
+        *reinterpret_cast<s16x4*>(p + (l & 15) * ld + 4 * (l >> 4)) = v;
+    }
+    static __device__ __forceinline__ void st_tr(elem* p, int ld, f32x4 c) {
+        const int l = lane_id();
+        elem* q = p + (4 * (l >> 4)) * ld + (l & 15);
+        q[0] = f2bf(c[0]); q[ld] = f2bf(c[1]); q[2 * ld] = f2bf(c[2]); q[3 * ld] = f2bf(c[3]);
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// reductions over the 4 lane groups that share one C-fragment column (lanes l, l^16, l^32, l^48)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ float colgroup_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    return v;
+}
+__device__ __forceinline__ float colgroup_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16));
+    v = fmaxf(v, __shfl_xor(v, 32));
+    return v;
+}
+// reduction over the 16 lanes that share one lane group (lanes with equal lane>>4)
+__device__ __forceinline__ float rowgroup_sum(float v) {
+    v += __shfl_xor(v, 1);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 8);
+    return v;
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// d/dx gelu_erf
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// ------------------------------------------------------------------------------------------
+// tile -> token-row mapping.  A tile is 64 rows = TS whole sequences of L tokens (TS = 64 / L).
+//   mode 0 (spatial):  sequence q = (b, c);  row (q, p) -> token b*T + c*N + p   = q*N + p
+//   mode 1 (spectral): sequence q = (b, n);  row (q, p) -> token b*T + p*N + n
+// Rows past TS*L, or sequences past nseq, are padding: loaded as zero, never stored.
+// ------------------------------------------------------------------------------------------
+struct TileMap {
+    int mode, L, TS, N, T, nseq;
+    __device__ __forceinline__ long token(int tile, int r) const {
+        const int s = r / L;
+        if (s >= TS) return -1;
+        const int q = tile * TS + s;
+        if (q >= nseq) return -1;
+        const int p = r - s * L;
+        if (mode == 0) return (long)q * N + p;
+        const int b = q / N, n = q - b * N;
+        return (long)b * T + (long)p * N + n;
+    }
+};
+
+}  // namespace msst

@@ -1,0 +1,427 @@
+// Forward kernels of the MaskedSST masked-pretraining hot path for gfx950 (MI355X).
+//
+//   tokenize_fwd   a1+a2+a3+a5  cube tile -> LN(P) -> per-block Linear(P->96) -> LN(96) -> +pos -> mask select
+//   block_fwd      a7-a10       fused pre-norm transformer block on a 64-row tile of whole sequences
+//                               (spatial and strided-spectral variants share the kernel via TileMap)
+//   head_fwd       a12-a14      gather masked tokens -> per-spectral-block Linear(96->P) -> masked L1
+//
+// Reference semantics (file:line under the reference repo) are cited at each kernel.
+#include "msst_dev.h"
+#include "msst_kernels.h"
+
+namespace msst {
+
+// ==========================================================================================
+// tokenizer: reference vit_spatial_spectral.py:197-222 (to_patch + embed),
+// vit_simmim_original.py:236-249,285 (pos add, mask-token select).
+// grid (S, B), 256 threads: 4 threads per spatial token, 24 output features each.
+// img [B][C][N] (N = H*W, patch 1x1), spectral block c holds bands c*P .. c*P+P-1: the tile
+// img[b, cP:(c+1)P, :] is P*N contiguous floats -> coalesced load into LDS.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
+    __shared__ float patch[16][64];
+    __shared__ float W[96][17];
+    __shared__ float bias[96];
+    const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int P = a.P, N = a.N;
+    const float* src = a.img + ((long)b * a.S + c) * P * N;
+    for (int i = tid; i < P * N; i += 256) patch[i / N][i % N] = src[i];
+    for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
+    if (tid < 96) bias[tid] = a.b_emb[c * 96 + tid];
+    __syncthreads();
+    const int n = tid >> 2, part = tid & 3;
+    if (n >= N) return;
+    // LN over the P raw pixel values (pre_norm, eps 1e-5)
+    float xn[16];
+    float mean = 0.f;
+    for (int k = 0; k < P; ++k) mean += patch[k][n];
+    mean /= P;
+    float var = 0.f;
+    for (int k = 0; k < P; ++k) { const float d = patch[k][n] - mean; var += d * d; }
+    const float rstd = rsqrtf(var / P + 1e-5f);
+    for (int k = 0; k < P; ++k) xn[k] = (patch[k][n] - mean) * rstd * a.pre_g[k] + a.pre_b[k];
+    // per-block Linear(P -> 96): this thread's 24 features
+    float e[24];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int d = part * 24 + i;
+        float acc = bias[d];
+        for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
+        e[i] = acc;
+        s += acc;
+    }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float m2 = s * (1.f / 96.f);
+    float v2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const float d = e[i] - m2; v2 += d * d; }
+    v2 += __shfl_xor(v2, 1); v2 += __shfl_xor(v2, 2);
+    const float rstd2 = rsqrtf(v2 * (1.f / 96.f) + 1e-5f);
+    const int t = c * N + n;
+    const bool masked = a.mask[(long)b * a.T + t] != 0;
+    float* dst = a.out + ((long)b * a.T + t) * 96 + part * 24;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int d = part * 24 + i;
+        float pos;
+        if (a.pos_split) pos = d < a.pos_split ? a.pos_a[n * a.pos_split + d] : a.pos_b[c * (96 - a.pos_split) + d - a.pos_split];
+        else pos = a.pos_a[(long)t * 96 + d];
+        const float tok = (e[i] - m2) * rstd2 * a.post_g[d] + a.post_b[d];
+        dst[i] = (masked ? a.mask_token[d] : tok) + pos;
+    }
+}
+
+// ==========================================================================================
+// fused transformer block, forward.  Reference vit_spatial_spectral.py:22-29 (PreNorm),
+// :47-78 (Attention: bias-free qkv, q|k|v chunks, head-major (h d), softmax(q k^T * dh^-0.5) v,
+// out-projection with bias), :32-44 (FeedForward, exact-erf GELU), :100-104 (residuals, no
+// final norm).  Dropout sites are identity (p = 0 / eval).
+//
+// One workgroup (4 waves) owns a 64-row tile of whole sequences; x stays on chip for the whole
+// block.  Per head:  phase A (wave <-> 16 of the 64 head channels): q,k,v^T = LN1(x) W^T into LDS;
+// phase B (wave <-> 16 query rows): S^T = k q^T, masked softmax over keys in registers, P -> LDS,
+// O = P v, out-projection accumulated in registers across heads.  Then residual, LN2, MLP, residual.
+// ==========================================================================================
+template <class P>
+struct FwdSmem {
+    typedef typename P::elem elem;
+    static constexpr int LDX = 96 + P::PADE;
+    static constexpr int LDH = 64 + P::PADE;
+    elem xn[64][LDX];
+    elem q[64][LDH];
+    elem k[64][LDH];
+    elem vt[64][LDH];
+    elem p[64][LDH];
+};
+
+template <class P>
+__global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(BlockArgs a) {
+    typedef typename P::elem elem;
+    typedef typename P::frag frag;
+    typedef FwdSmem<P> SM;
+    constexpr int KS = P::KS, LDX = SM::LDX, LDH = SM::LDH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int H = a.H, inner = H * 64;
+    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
+    const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
+    const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
+    const elem* w2 = reinterpret_cast<const elem*>(a.w.w2);
+    const TileMap tm = a.tm;
+    const int L = tm.L;
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        // ---------------- LN1 (4 threads per row, 24 features each) ----------------
+        {
+            const int r = tid >> 2, part = tid & 3;
+            const long tok = tm.token(tile, r);
+            float v[24];
+            if (tok >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) v[i] = 0.f;
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) s += v[i];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            const float mean = s * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int d = part * 24 + i;
+                sm.xn[r][d] = P::cvt((v[i] - mean) * rstd * a.w.ln1_g[d] + a.w.ln1_b[d]);
+            }
+        }
+        __syncthreads();
+
+        f32x4 oacc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) oacc[i] = zero4();
+
+        for (int h = 0; h < H; ++h) {
+            // ---------------- phase A: q, k, v^T for head h ----------------
+            {
+                f32x4 cq[4], ck[4], cv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
+                const elem* wq = wqkv + (long)((0 * H + h) * 64 + wave * 16) * 96;
+                const elem* wk = wqkv + (long)((1 * H + h) * 64 + wave * 16) * 96;
+                const elem* wv = wqkv + (long)((2 * H + h) * 64 + wave * 16) * 96;
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 96; k0 += KS) {
+                    const frag aq = P::ld_kc(wq + k0, 96);
+                    const frag ak = P::ld_kc(wk + k0, 96);
+                    const frag av = P::ld_kc(wv + k0, 96);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag xb = P::ld_kc(&sm.xn[t * 16][k0], LDX);
+                        cq[t] = P::mma(aq, xb, cq[t]);  // C[i = d][j = row]
+                        ck[t] = P::mma(ak, xb, ck[t]);
+                        cv[t] = P::mma(xb, av, cv[t]);  // C[i = row][j = d]
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    P::st_nat(&sm.q[t * 16][wave * 16], LDH, cq[t]);   // q[row][d]
+                    P::st_nat(&sm.k[t * 16][wave * 16], LDH, ck[t]);   // k[row][d]
+                    P::st_nat(&sm.vt[wave * 16][t * 16], LDH, cv[t]);  // vt[d][row]
+                }
+            }
+            __syncthreads();
+            // ---------------- phase B: attention for query rows wave*16 .. +15 ----------------
+            {
+                f32x4 s[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s[t] = zero4();
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 64; k0 += KS) {
+                    const frag qb = P::ld_kc(&sm.q[wave * 16][k0], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) s[t] = P::mma(P::ld_kc(&sm.k[t * 16][k0], LDH), qb, s[t]);  // C[i = key][j = query]
+                }
+                const int qseq = (wave * 16 + c) / L;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * 16 + 4 * g + r;
+                        const float v = (key / L == qseq) ? s[t][r] * a.scale : -INFINITY;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = colgroup_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = expf(s[t][r] - mx);  // exp(-inf) = 0 for masked keys
+                        s[t][r] = e;
+                        sum += e;
+                    }
+                sum = colgroup_sum(sum);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P::st_nat(&sm.p[wave * 16][t * 16], LDH, s[t] * inv);  // p[query][key]
+                __builtin_amdgcn_wave_barrier();
+                f32x4 o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = zero4();
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 64; k0 += KS) {
+                    const frag pb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);  // C[i = d][j = query]
+                }
+                // O over this wave's (now dead) q rows: o[query][d]
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P::st_nat(&sm.q[wave * 16][t * 16], LDH, o[t]);
+                __builtin_amdgcn_wave_barrier();
+                // out-projection, accumulated over heads: C[i = m][j = query], A = Wout[m][h*64 + d]
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 64; k0 += KS) {
+                    const frag ob = P::ld_kc(&sm.q[wave * 16][k0], LDH);
+#pragma unroll
+                    for (int mt = 0; mt < 6; ++mt)
+                        oacc[mt] = P::mma(P::ld_kc(wout + (long)(mt * 16) * inner + h * 64 + k0, inner), ob, oacc[mt]);
+                }
+            }
+            __syncthreads();
+        }
+
+        // ---------------- residual + LN2 + MLP + residual (wave owns 16 rows) ----------------
+        const int row = wave * 16 + c;
+        const long tok = tm.token(tile, row);
+        float x1[6][4];
+        float s1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 xr = zero4();
+            if (tok >= 0) xr = *reinterpret_cast<const f32x4*>(a.x + tok * 96 + m0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x1[mt][r] = oacc[mt][r] + a.w.bo[m0 + r] + xr[r];
+                s1 += x1[mt][r];
+            }
+            if (a.x1 && tok >= 0) {
+                f32x4 o4 = {x1[mt][0], x1[mt][1], x1[mt][2], x1[mt][3]};
+                *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+            }
+        }
+        s1 = colgroup_sum(s1);
+        const float mean = s1 * (1.f / 96.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = x1[mt][r] - mean; vs += d * d; }
+        vs = colgroup_sum(vs);
+        const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 n4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) n4[r] = (x1[mt][r] - mean) * rstd * a.w.ln2_g[m0 + r] + a.w.ln2_b[m0 + r];
+            P::st_nat(&sm.xn[wave * 16][mt * 16], LDX, n4);  // xn2[row][m] (wave-private rows)
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 hh[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hh[nt] = zero4();
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 96; k0 += KS) {
+            const frag xb = P::ld_kc(&sm.xn[wave * 16][k0], LDX);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(P::ld_kc(w1 + (long)(nt * 16) * 96 + k0, 96), xb, hh[nt]);  // C[i = n][j = row]
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = nt * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_erf(hh[nt][r] + a.w.b1[n0 + r]);
+            P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);  // h[row][n]
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 yy[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) yy[mt] = zero4();
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 64; k0 += KS) {
+            const frag hb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(P::ld_kc(w2 + (long)(mt * 16) * 64 + k0, 64), hb, yy[mt]);  // C[i = m][j = row]
+        }
+        if (tok >= 0) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int m0 = mt * 16 + 4 * g;
+                f32x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + a.w.b2[m0 + r] + x1[mt][r];
+                *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template __global__ void block_fwd_kernel<PF32>(BlockArgs);
+template __global__ void block_fwd_kernel<PBF16>(BlockArgs);
+
+// ==========================================================================================
+// head: reference vit_simmim_original.py:314 (gather), :21-40 + :317-330 (BlockwiseToPixels,
+// block id = idx // N), :335 (target = raw pixels of the masked patch), :338 (mean |.| / K).
+// grid (ceil(K/64), B), 256 threads: 4 threads per masked entry, 24 features each.
+// Writes per-workgroup partial |.| sums (deterministic two-stage reduction) and
+// dpred = sign(pred - target) for the backward.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void head_fwd_kernel(HeadArgs a) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, e = tid >> 2, part = tid & 3;
+    const int b = blockIdx.y, k = blockIdx.x * 64 + e;
+    const int P = a.P;
+    float lsum = 0.f;
+    if (k < a.K) {
+        const int t = a.idx[(long)b * a.K + k];
+        const int c = t / a.N, n = t - c * a.N;
+        const float* enc = a.y + ((long)b * a.T + t) * 96 + part * 24;
+        float ev[24];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const f32x4 t4 = reinterpret_cast<const f32x4*>(enc)[i];
+            ev[4*i] = t4[0]; ev[4*i+1] = t4[1]; ev[4*i+2] = t4[2]; ev[4*i+3] = t4[3];
+        }
+        const int wc = a.per_block ? c : 0;
+        const float* Wp = a.w_pix + (long)wc * P * 96 + part * 24;
+        for (int p = 0; p < P; ++p) {
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) acc += Wp[p * 96 + i] * ev[i];
+            acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+            if (part == 0) {
+                const float pred = acc + a.b_pix[wc * P + p];
+                const float target = a.img[((long)b * a.S * P + (long)c * P + p) * a.N + n];
+                const float d = pred - target;
+                lsum += fabsf(d);
+                a.dpred[((long)b * a.K + k) * P + p] = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+                if (a.pred) a.pred[((long)b * a.K + k) * P + p] = pred;
+            }
+        }
+    }
+    // workgroup reduction (fixed order)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if ((tid & 63) == 0) red[tid >> 6] = lsum;
+    __syncthreads();
+    if (tid == 0) a.partial[blockIdx.y * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// final loss: sum partials in a fixed order, scale by 1 / (B*K*P) / K
+__global__ __launch_bounds__(256) void loss_reduce_kernel(const float* partial, int n, float scale, float* loss) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *loss = (float)(red[0] * (double)scale);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int launch_tokenize_fwd(const TokArgs& a, hipStream_t st) {
+    if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tokenize_fwd_kernel, dim3(a.S, a.B), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+template <class P>
+static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(FwdSmem<P>);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<P>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(block_fwd_kernel<P>, dim3(grid), dim3(256), smem, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
+    if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
+    int grid = a.ntiles < a.max_grid ? a.ntiles : a.max_grid;
+    if (grid < 1) return 0;
+    return prec == MSST_PREC_F32 ? launch_block_fwd_t<PF32>(a, grid, st) : launch_block_fwd_t<PBF16>(a, grid, st);
+}
+
+int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {
+    if (a.P > 16) return MSST_ERR_UNSUPPORTED;
+    dim3 grid((a.K + 63) / 64, a.B);
+    hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(256), 0, st, a);
+    const int np = grid.x * grid.y;
+    const float scale = 1.0f / ((float)a.B * (float)a.K * (float)a.P) / (float)a.K;
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, a.partial, np, scale, loss);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst

@@ -1,0 +1,69 @@
+// Internal kernel argument blocks + launcher prototypes (C++ side of the C-ABI in include/msst.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "msst_dev.h"
+
+#define MSST_PREC_F32 0
+#define MSST_PREC_BF16 1
+#define MSST_ERR_UNSUPPORTED (-2)
+#define MSST_ERR_BADARG (-3)
+
+namespace msst {
+
+// Per-block weights.  The big matrices are "prepped" copies in the operand element type
+// (fp32 or bf16), each also in transposed form for the backward GEMMs; the small vectors are fp32.
+struct BlockWeights {
+    const void* wqkv;   // [3*H*64][96]   rows: q heads | k heads | v heads (reference chunk order)
+    const void* wout;   // [96][H*64]
+    const void* w1;     // [64][96]
+    const void* w2;     // [96][64]
+    const void* wqkvT;  // [96][3*H*64]
+    const void* woutT;  // [H*64][96]
+    const void* w1T;    // [96][64]
+    const void* w2T;    // [64][96]
+    const float* ln1_g; const float* ln1_b; const float* bo;
+    const float* ln2_g; const float* ln2_b; const float* b1; const float* b2;
+};
+
+struct BlockArgs {
+    BlockWeights w;
+    const float* x;   // [tokens][96] block input (residual stream, fp32)
+    float* y;         // [tokens][96] block output
+    float* x1;        // [tokens][96] mid-block residual (x + attn), saved for the backward; may be null
+    TileMap tm;
+    int ntiles, max_grid, H;
+    float scale;      // dim_head^-0.5
+};
+
+struct TokArgs {
+    const float* img;        // [B][S*P][N]
+    const float* pre_g; const float* pre_b;     // [P]
+    const float* w_emb;      // [S][96][P]
+    const float* b_emb;      // [S][96]
+    const float* post_g; const float* post_b;   // [96]
+    const float* pos_a;      // pos_split == 0: learned table [T][96]; else spatial table [N][pos_split]
+    const float* pos_b;      // pos_split != 0: spectral table [S][96 - pos_split]
+    const float* mask_token; // [96]
+    const uint8_t* mask;     // [B][T] (1 = masked); all-zero for the classification path
+    float* out;              // [B][T][96]
+    int B, S, N, T, P, pos_split;
+};
+
+struct HeadArgs {
+    const float* y;      // [B][T][96] encoder output
+    const float* img;    // [B][S*P][N]
+    const int* idx;      // [B][K] masked token indices
+    const float* w_pix;  // [S or 1][P][96]
+    const float* b_pix;  // [S or 1][P]
+    float* dpred;        // [B][K][P] sign(pred - target)
+    float* pred;         // optional [B][K][P]
+    float* partial;      // [B * ceil(K/64)]
+    int B, S, N, T, P, K, per_block;
+};
+
+int launch_tokenize_fwd(const TokArgs& a, hipStream_t st);
+int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
+int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st);
+
+}  // namespace msst

@@ -1,0 +1,212 @@
+"""Host-side engine: owns the flat parameter buffers, the operand-layout weight copies and the
+launch sequence of the HIP kernels (through the C-ABI in ``libmsst.so``) for one model.
+
+PyTorch is used for device memory (``torch.empty``), streams and autograd bookkeeping only; all
+arithmetic of the hot path runs in the kernels under ``maskedsst_amd/csrc``.
+"""
+import ctypes
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MsstBlockWeights, MsstPrepJob, PREC_BF16, PREC_F32, MODE_SPATIAL, MODE_SPECTRAL
+from .flat import FlatParams
+
+D = 96
+DH = 64
+MLP = 64
+
+
+def _prec_of(name):
+    name = (name or os.environ.get("MSST_PRECISION", "bf16")).lower()
+    if name in ("fp32", "f32", "32-true", "float32"):
+        return PREC_F32
+    if name in ("bf16", "bf16-mixed", "bfloat16"):
+        return PREC_BF16
+    raise ValueError(f"unknown precision {name!r} (use 'bf16' or 'fp32')")
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, encoder, mim):
+        self.enc = encoder
+        self.mim = mim
+        self.lib = _lib.load()
+        self.fp = FlatParams(encoder, mim)
+        self.prec = _prec_of(getattr(encoder, "precision", None))
+        self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
+        self._wbuf = None
+        self._jobs = None
+        self._bw = None
+        self._zero_mask = None
+
+    # ------------------------------------------------------------------ setup
+    @property
+    def S(self):
+        return self.enc.num_spectral_patches
+
+    @property
+    def N(self):
+        return self.enc.num_spatial_patches
+
+    @property
+    def P(self):
+        return self.enc.pixels_per_patch
+
+    def set_precision(self, name):
+        prec = _prec_of(name)
+        if prec != self.prec:
+            self.prec = prec
+            self._wbuf = None
+
+    def _require_cuda(self, t):
+        if not t.is_cuda:
+            raise RuntimeError(
+                "maskedsst_amd runs on an MI355X only (tensor is on %s); there is no CPU fallback" % t.device)
+
+    def ensure(self):
+        """flat buffers + operand-layout weight storage + prep job table (rebuilt if params moved)"""
+        if self.fp.stale():
+            self.fp.flatten()
+            self._wbuf = None
+        if self._wbuf is None:
+            self._build_weight_storage()
+
+    def _layers(self):
+        """[(stack name, layer index)] in forward order"""
+        L = self.enc.depth
+        return [("spatial", l) for l in range(L)] + [("spectral", l) for l in range(L)]
+
+    def _build_weight_storage(self):
+        dev = self.fp.flat.device
+        self._require_cuda(self.fp.flat)
+        H = self.enc.heads
+        inner = H * DH
+        esz = 4 if self.prec == PREC_F32 else 2
+        mats = [("wqkv", 3 * inner, D), ("wout", D, inner), ("w1", MLP, D), ("w2", D, MLP)]
+        per_layer = sum(2 * r * c for _, r, c in mats)
+        layers = self._layers()
+        self._wbuf = torch.empty(per_layer * len(layers) * esz, dtype=torch.uint8, device=dev)
+        base = self._wbuf.data_ptr()
+        jobs = (MsstPrepJob * (8 * len(layers)))()
+        self._bw = []
+        off = 0
+        j = 0
+        maxel = 0
+        for sname, l in layers:
+            bw = MsstBlockWeights()
+            for name, r, c in mats:
+                src = self.fp.ptr(f"{sname}.{l}.{name}")
+                for tr in (0, 1):
+                    dst = base + off * esz
+                    jobs[j].src, jobs[j].dst, jobs[j].rows, jobs[j].cols, jobs[j].transpose = src, dst, r, c, tr
+                    setattr(bw, name + ("T" if tr else ""), dst)
+                    off += r * c
+                    j += 1
+                    maxel = max(maxel, r * c)
+            for name in ("ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2"):
+                setattr(bw, name, self.fp.ptr(f"{sname}.{l}.{name}"))
+            self._bw.append(bw)
+        raw = bytes(jobs)
+        self._jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._njobs = j
+        self._maxel = maxel
+
+    def prep_weights(self):
+        """fp32 master weights -> operand layout (one launch); call after every parameter update"""
+        self.ensure()
+        _lib.check(self.lib.msst_prep_weights(_p(self._jobs), self._njobs, self._maxel, self.prec, _stream()),
+                   "msst_prep_weights")
+
+    # ------------------------------------------------------------------ forward pieces
+    def tokenize(self, img, mask_u8=None, with_pos=True):
+        """img [B, C, H, W] fp32 cuda -> tokens [B, T, 96] (pos added, mask token substituted)"""
+        self._require_cuda(img)
+        self.ensure()
+        B = img.shape[0]
+        S, N, P = self.S, self.N, self.P
+        T = S * N
+        img = img.contiguous().float()
+        out = torch.empty(B, T, D, dtype=torch.float32, device=img.device)
+        if mask_u8 is None:
+            if self._zero_mask is None or self._zero_mask.numel() < B * T:
+                self._zero_mask = torch.zeros(B * T, dtype=torch.uint8, device=img.device)
+            mask_u8 = self._zero_mask
+        fp = self.fp
+        if not with_pos:
+            if getattr(self, "_zero_pos", None) is None or self._zero_pos.numel() < T * D:
+                self._zero_pos = torch.zeros(T * D, dtype=torch.float32, device=img.device)
+            pos_a, pos_b, split = self._zero_pos.data_ptr(), 0, 0
+        elif self.enc.spectral_pos_embed:
+            split = self.enc.pos_embed.shape[-1]
+            pos_a, pos_b = fp.ptr("pos_embed"), fp.ptr("channel_embed")
+        else:
+            split = 0
+            pos_a, pos_b = fp.ptr("pos_embedding"), 0
+        mt = fp.ptr("mask_token") if self.mim is not None else fp.ptr("post_b")
+        V = ctypes.c_void_p
+        _lib.check(self.lib.msst_tokenize_fwd(
+            _p(img), V(fp.ptr("pre_g")), V(fp.ptr("pre_b")), V(fp.ptr("embed.w.0")), V(fp.ptr("embed.b.0")),
+            V(fp.ptr("post_g")), V(fp.ptr("post_b")), V(pos_a), V(pos_b), split, V(mt), _p(mask_u8), _p(out),
+            B, S, N, P, _stream()), "msst_tokenize_fwd")
+        return out
+
+    def blocks_fwd(self, x0, save=True):
+        """run the 2*depth fused blocks; returns (list of activations [x0 .. x_2L], list of x1)"""
+        B = x0.shape[0]
+        S, N, H = self.S, self.N, self.enc.heads
+        acts = [x0]
+        x1s = []
+        x = x0
+        for i, (sname, l) in enumerate(self._layers()):
+            y = torch.empty_like(x)
+            x1 = torch.empty_like(x) if save else None
+            mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+            _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
+                                               self.prec, self.max_grid, _stream()), "msst_block_fwd")
+            acts.append(y)
+            x1s.append(x1)
+            x = y
+        return acts, x1s
+
+    def head_fwd(self, y, img, idx32, want_pred=False):
+        B, T, _ = y.shape
+        S, N, P = self.S, self.N, self.P
+        K = idx32.shape[1]
+        dev = y.device
+        dpred = torch.empty(B, K, P, dtype=torch.float32, device=dev)
+        pred = torch.empty(B, K, P, dtype=torch.float32, device=dev) if want_pred else None
+        partial = torch.empty(B * ((K + 63) // 64), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        per_block = 1 if hasattr(self.mim.to_pixels, "layers") else 0
+        V = ctypes.c_void_p
+        _lib.check(self.lib.msst_head_fwd(
+            _p(y), _p(img), _p(idx32), V(self.fp.ptr("to_pixels.w.0")), V(self.fp.ptr("to_pixels.b.0")), per_block,
+            _p(dpred), _p(pred), _p(partial), _p(loss), B, S, N, P, K, _stream()), "msst_head_fwd")
+        return loss, dpred, pred
+
+    # ------------------------------------------------------------------ staged forward (tests / debugging)
+    def simmim_forward_stages(self, img, bool_mask, idx):
+        """Forward only, returning the intermediates the golden fixtures pin."""
+        self._require_cuda(img)
+        self.prep_weights()
+        dev = img.device
+        img = img.contiguous().float()
+        mask_u8 = bool_mask.to(device=dev, dtype=torch.uint8).contiguous()
+        idx32 = idx.to(device=dev, dtype=torch.int32).contiguous()
+        tok_embed = self.tokenize(img, None, with_pos=False)
+        x0 = self.tokenize(img, mask_u8)
+        acts, x1s = self.blocks_fwd(x0)
+        loss, dpred, pred = self.head_fwd(acts[-1], img, idx32, want_pred=True)
+        L = self.enc.depth
+        return dict(loss=loss, tok_embed=tok_embed, tok_masked=x0, after_spatial=acts[L], enc_out=acts[-1],
+                    pred=pred, dpred=dpred, acts=acts, x1s=x1s)
