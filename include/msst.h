@@ -94,43 +94,50 @@ int msst_head_fwd(const float* y, const float* img, const int32_t* idx, const fl
                   const float* b_pix, int per_block, float* dpred, float* pred, float* partial,
                   float* loss, int B, int S, int N, int P, int K, void* stream);
 
-/* ---- backward (a15) ---- */
+/* ---- backward (a15: what autograd does for the reference at pretrain.py:116) ---- */
 
-/* d(loss)/d(encoder output) and to_pixels grads.  csr_ptr [B][T+1], csr_pos [B][K]: for each token
- * the positions k with idx[b][k] == token (duplicates allowed -- the reference's misaligned index
- * slicing produces them).  dy [B][T][96] is fully written.
- * slab: [S][nchunk][P*96 + P] partial to_pixels grads, reduced by msst_reduce_slabs. */
+/* d(loss)/d(encoder output) through the gather + to_pixels, and the to_pixels grads.
+ * csr_ptr [B][T+1], csr_pos [B][K]: for each token the positions k with idx[b][k] == token
+ * (duplicates allowed -- the reference's misaligned index slicing produces them).
+ * gscale = 1 / (B*K*P) / K; gout = optional device scalar d(final)/d(loss) multiplied in.
+ * dy [B][T][96] is fully written.
+ * slab: S * nchunk * (P*96 + P) floats of scratch.  dw_pix / db_pix laid out like w_pix / b_pix. */
 int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, const int32_t* csr_pos,
-                  const float* w_pix, int per_block, float gscale, float* dy, float* slab, int nchunk,
-                  int B, int S, int N, int P, int K, void* stream);
+                  const float* w_pix, int per_block, float gscale, const float* gout, float* dy, float* slab,
+                  int nchunk, float* dw_pix, float* db_pix, int B, int S, int N, int P, int K, void* stream);
 
-/* MLP half of a block: dy -> dx1 (= d/d(x + attn)), weight-grad partial slabs [grid][MSST_MLP_SLAB]. */
+/* Gradient destinations of one transformer block (fp32, shapes of the reference parameters). */
+typedef struct MsstBlockGrads {
+    float* ln1_g; float* ln1_b; float* wqkv; float* wout; float* bo;
+    float* ln2_g; float* ln2_b; float* w1; float* b1; float* w2; float* b2;
+} MsstBlockGrads;
+
+/* Scratch sizes (floats) for msst_block_bwd */
 #define MSST_MLP_SLAB (64 * 96 + 96 * 64 + 64 + 96 + 96 + 96)
-int msst_block_bwd_mlp(const MsstBlockWeights* w /*host*/, const float* x1, const float* dy, float* dx1,
-                       float* slab, int grid, int mode, int B, int S, int N, int prec, void* stream);
-
-/* attention half: recompute q,k,v,P from x, consume da = dx1; per (chunk, head) workgroups.
- * dxn_part [heads][tokens][96] (elem type) receives per-head partial d/d(LN1(x));
- * slab [nchunk][heads][MSST_ATTN_SLAB] receives dWq|dWk|dWv [3][64][96] and dWout_h [96][64]. */
 #define MSST_ATTN_SLAB (3 * 64 * 96 + 96 * 64)
-int msst_block_bwd_attn(const MsstBlockWeights* w /*host*/, const float* x, const float* da, void* dxn_part,
-                        float* slab, int nchunk, int mode, int B, int S, int N, int heads, int prec,
-                        void* stream);
+#define MSST_LN1_SLAB 288
 
-/* dx = dx1 + LN1_bwd(sum_h dxn_part[h]; x); LN1 gamma/beta grad partials slab [grid][192]. */
-int msst_block_bwd_ln1(const MsstBlockWeights* w /*host*/, const float* x, const float* dx1,
-                       const void* dxn_part, float* dx, float* slab, int grid, int B, int S, int N,
-                       int heads, int prec, void* stream);
-
-/* out[i] (+)= sum_{s<nslab} slab[s*stride + i], i < n  (fixed order, deterministic). */
-int msst_reduce_slabs(const float* slab, int nslab, long stride, float* out, int n, int accumulate,
-                      void* stream);
+/* Backward of one fused block: given the saved block input x, the saved mid residual x1 and dy,
+ * writes dx and every parameter gradient of the block.  Internally: MLP half (recompute from x1)
+ * -> attention half, one workgroup per (tile chunk, head), weight grads in registers -> LN1
+ * backward + residual; partial-gradient slabs are reduced in a fixed order (deterministic).
+ * Workspace (caller-owned, device): dx1 [tokens][96] f32; dxn_part heads*tokens*96 elems
+ * (f32 or bf16 by prec); slab max(grid_rows*MSST_MLP_SLAB, nchunk*heads*MSST_ATTN_SLAB,
+ * grid_rows*MSST_LN1_SLAB) floats. */
+int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/, const float* x,
+                   const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
+                   int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,
+                   void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.
- * slab [S][nchunk][MSST_TOK_SLAB(N,P)] partials over batch chunks. */
+ * slab: S * nchunk * (N*96 + 96*P + 4*96 + 32) floats + S*N*96 floats (position staging).
+ * dpos_a / dpos_b follow pos_a / pos_b of msst_tokenize_fwd; dmask_token may be null. */
 int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,
                       const float* b_emb, const float* post_g, const float* post_b, const uint8_t* mask,
-                      const float* dx0, float* slab, int nchunk, int B, int S, int N, int P, void* stream);
+                      const float* dx0, float* slab, int nchunk, float* dpre_g, float* dpre_b,
+                      float* dw_emb, float* db_emb, float* dpost_g, float* dpost_b, float* dpos_a,
+                      float* dpos_b, int pos_split, float* dmask_token, int B, int S, int N, int P,
+                      void* stream);
 
 /* Fused AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, src/utils.py:36-45), with the
  * reference's value clamp of the gradient (pretrain.py:71-73) when clamp > 0. */

@@ -16,6 +16,7 @@ MODE_SPATIAL = 0
 MODE_SPECTRAL = 1
 MLP_SLAB = 64 * 96 + 96 * 64 + 64 + 96 + 96 + 96
 ATTN_SLAB = 3 * 64 * 96 + 96 * 64
+LN1_SLAB = 288
 
 
 class MsstError(RuntimeError):
@@ -33,6 +34,11 @@ class MsstBlockWeights(Structure):
         "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2")]
 
 
+class MsstBlockGrads(Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "ln1_g", "ln1_b", "wqkv", "wout", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2")]
+
+
 _P = c_void_p
 _SIGS = {
     "msst_version": (c_int, []),
@@ -43,16 +49,11 @@ _SIGS = {
                                c_int, c_int, _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                               c_int, _P]),
-    "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, c_int, c_int, c_int, c_int,
+    "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
                               c_int, c_int, _P]),
-    "msst_block_bwd_mlp": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, c_int, c_int, c_int, c_int,
-                                   c_int, c_int, _P]),
-    "msst_block_bwd_attn": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, c_int, c_int, c_int, c_int,
-                                    c_int, c_int, c_int, _P]),
-    "msst_block_bwd_ln1": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, _P, _P, c_int, c_int, c_int,
-                                   c_int, c_int, c_int, _P]),
-    "msst_reduce_slabs": (c_int, [_P, c_int, c_long, _P, c_int, c_int, _P]),
-    "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int, c_int, c_int, c_int, c_int, _P]),
+    "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "msst_adamw": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                            c_float, c_float, _P]),
 }

@@ -111,4 +111,117 @@ int msst_head_fwd(const float* y, const float* img, const int32_t* idx, const fl
     return fail(launch_head_fwd(a, loss, (hipStream_t)stream), "msst_head_fwd");
 }
 
+int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, const int32_t* csr_pos,
+                  const float* w_pix, int per_block, float gscale, const float* gout, float* dy, float* slab,
+                  int nchunk, float* dw_pix, float* db_pix, int B, int S, int N, int P, int K, void* stream) {
+    if (nchunk < 1) return fail(MSST_ERR_BADARG, "msst_head_bwd");
+    hipStream_t st = (hipStream_t)stream;
+    HeadBwdArgs a;
+    a.y = y; a.dpred = dpred; a.csr_ptr = csr_ptr; a.csr_pos = csr_pos; a.w_pix = w_pix; a.dy = dy; a.slab = slab;
+    a.gscale = gscale; a.gout = gout; a.B = B; a.S = S; a.N = N; a.T = S * N; a.P = P; a.K = K; a.per_block = per_block;
+    int rc = launch_head_bwd(a, nchunk, st);
+    if (rc) return fail(rc, "msst_head_bwd");
+    const long ss = (long)P * 96 + P;
+    if (per_block) {
+        rc = launch_reduce_slabs(slab, S, nchunk * ss, nchunk, ss, dw_pix, (long)P * 96, P * 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + P * 96, S, nchunk * ss, nchunk, ss, db_pix, P, P, 0, st);
+    } else {
+        rc = launch_reduce_slabs(slab, 1, 0, S * nchunk, ss, dw_pix, 0, P * 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + P * 96, 1, 0, S * nchunk, ss, db_pix, 0, P, 0, st);
+    }
+    return fail(rc, "msst_head_bwd(reduce)");
+}
+
+int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
+                   const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
+                   int nchunk, int mode, int B, int S, int N, int heads, int prec, void* stream) {
+    if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
+    if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
+    hipStream_t st = (hipStream_t)stream;
+    const long ntok = (long)B * S * N;
+    const BlockWeights bw = to_bw(w);
+    // 1. MLP half: dy -> dx1, slabs -> dW1 dW2 db1 db2 dln2
+    {
+        MlpBwdArgs a;
+        a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab; a.ntok = ntok;
+        const int ntiles = (int)((ntok + 63) / 64);
+        const int grid = grid_rows < ntiles ? grid_rows : ntiles;
+        int rc = launch_block_bwd_mlp(a, grid, prec, st);
+        if (rc) return fail(rc, "msst_block_bwd(mlp)");
+        const long ss = MSST_MLP_SLAB_N;
+        rc = launch_reduce_slabs(slab, 1, 0, grid, ss, g->w1, 0, 6144, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 6144, 1, 0, grid, ss, g->w2, 0, 6144, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 12288, 1, 0, grid, ss, g->b1, 0, 64, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 64, 1, 0, grid, ss, g->b2, 0, 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 160, 1, 0, grid, ss, g->ln2_g, 0, 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 256, 1, 0, grid, ss, g->ln2_b, 0, 96, 0, st);
+        if (rc) return fail(rc, "msst_block_bwd(mlp reduce)");
+    }
+    // 2. attention half, per (chunk, head)
+    {
+        AttnBwdArgs a;
+        a.w = bw; a.x = x; a.da = dx1; a.dxn_part = dxn_part; a.slab = slab;
+        a.tm = make_tilemap(mode, B, S, N);
+        a.ntiles = ntiles_of(a.tm);
+        a.H = heads; a.ntok = ntok; a.scale = 0.125f;
+        const int nc = nchunk < a.ntiles ? nchunk : a.ntiles;
+        int rc = launch_block_bwd_attn(a, nc, prec, st);
+        if (rc) return fail(rc, "msst_block_bwd(attn)");
+        rc = launch_attn_slab_reduce(slab, nc, heads, g->wqkv, g->wout, st);
+        if (rc) return fail(rc, "msst_block_bwd(attn reduce)");
+    }
+    // 3. LN1 backward + residual
+    {
+        Ln1BwdArgs a;
+        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab; a.ntok = ntok; a.H = heads;
+        const int ntiles = (int)((ntok + 63) / 64);
+        const int grid = grid_rows < ntiles ? grid_rows : ntiles;
+        int rc = launch_block_bwd_ln1(a, grid, prec, st);
+        if (rc) return fail(rc, "msst_block_bwd(ln1)");
+        rc = launch_reduce_slabs(slab, 1, 0, grid, 288, g->ln1_g, 0, 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 96, 1, 0, grid, 288, g->ln1_b, 0, 96, 0, st);
+        if (!rc) rc = launch_reduce_slabs(slab + 192, 1, 0, grid, 288, g->bo, 0, 96, 0, st);
+        if (rc) return fail(rc, "msst_block_bwd(ln1 reduce)");
+    }
+    return 0;
+}
+
+int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,
+                      const float* b_emb, const float* post_g, const float* post_b, const uint8_t* mask,
+                      const float* dx0, float* slab, int nchunk, float* dpre_g, float* dpre_b,
+                      float* dw_emb, float* db_emb, float* dpost_g, float* dpost_b, float* dpos_a,
+                      float* dpos_b, int pos_split, float* dmask_token, int B, int S, int N, int P,
+                      void* stream) {
+    if (nchunk < 1) return fail(MSST_ERR_BADARG, "msst_tokenize_bwd");
+    hipStream_t st = (hipStream_t)stream;
+    TokBwdArgs a;
+    a.img = img; a.pre_g = pre_g; a.pre_b = pre_b; a.w_emb = w_emb; a.b_emb = b_emb; a.post_g = post_g;
+    a.post_b = post_b; a.mask = mask; a.dx0 = dx0; a.slab = slab; a.B = B; a.S = S; a.N = N; a.T = S * N; a.P = P;
+    int rc = launch_tokenize_bwd(a, nchunk, st);
+    if (rc) return fail(rc, "msst_tokenize_bwd");
+    const long ss = (long)N * 96 + 96 * P + 96 * 4 + 32;
+    const long bs = (long)nchunk * ss;
+    float* stage = slab + (long)S * nchunk * ss;  // [S][N][96] position-gradient staging
+    // per spectral block: position rows, embed weight, embed bias
+    float* dpos_dst = pos_split ? stage : dpos_a;
+    rc = launch_reduce_slabs(slab, S, bs, nchunk, ss, dpos_dst, (long)N * 96, N * 96, 0, st);
+    if (!rc) rc = launch_reduce_slabs(slab + N * 96, S, bs, nchunk, ss, dw_emb, 96 * P, 96 * P, 0, st);
+    const long v0 = (long)N * 96 + 96 * P;
+    if (!rc) rc = launch_reduce_slabs(slab + v0, S, bs, nchunk, ss, db_emb, 96, 96, 0, st);
+    // shared across blocks
+    if (!rc) rc = launch_reduce_slabs(slab + v0 + 96, 1, 0, S * nchunk, ss, dpost_g, 0, 96, 0, st);
+    if (!rc) rc = launch_reduce_slabs(slab + v0 + 192, 1, 0, S * nchunk, ss, dpost_b, 0, 96, 0, st);
+    if (!rc && dmask_token) rc = launch_reduce_slabs(slab + v0 + 288, 1, 0, S * nchunk, ss, dmask_token, 0, 96, 0, st);
+    if (!rc) rc = launch_reduce_slabs(slab + v0 + 384, 1, 0, S * nchunk, ss, dpre_g, 0, P, 0, st);
+    if (!rc) rc = launch_reduce_slabs(slab + v0 + 384 + 16, 1, 0, S * nchunk, ss, dpre_b, 0, P, 0, st);
+    if (!rc && pos_split) rc = launch_pos_split(stage, S, N, pos_split, dpos_a, dpos_b, st);
+    return fail(rc, "msst_tokenize_bwd(reduce)");
+}
+
+int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, float clamp, float gscale, void* stream) {
+    return fail(launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, clamp, gscale,
+                             (hipStream_t)stream), "msst_adamw");
+}
+
 }  // extern "C"

@@ -1,11 +1,969 @@
-// TEMPORARY stubs (replaced by the backward kernels).
-#include "../../include/msst.h"
-extern "C" {
-int msst_head_bwd(const float*, const float*, const int32_t*, const int32_t*, const float*, int, float, float*, float*, int, int, int, int, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_block_bwd_mlp(const MsstBlockWeights*, const float*, const float*, float*, float*, int, int, int, int, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_block_bwd_attn(const MsstBlockWeights*, const float*, const float*, void*, float*, int, int, int, int, int, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_block_bwd_ln1(const MsstBlockWeights*, const float*, const float*, const void*, float*, float*, int, int, int, int, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_reduce_slabs(const float*, int, long, float*, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_tokenize_bwd(const float*, const float*, const float*, const float*, const float*, const float*, const float*, const uint8_t*, const float*, float*, int, int, int, int, int, void*) { return MSST_ERR_UNSUPPORTED; }
-int msst_adamw(float*, const float*, float*, float*, long, float, float, float, float, float, int, float, float, void*) { return MSST_ERR_UNSUPPORTED; }
+// Backward kernels of the MaskedSST masked-pretraining hot path for gfx950 (row a15 of the scope
+// table: what PyTorch autograd does for the reference at pretrain.py:116).
+//
+//   head_bwd        d(loss)/d(encoder out) through the masked gather + BlockwiseToPixels, to_pixels grads
+//   block_bwd_mlp   FeedForward + LN2 + residual of one block (recompute from the saved x1)
+//   block_bwd_attn  attention of one block, one workgroup per (tile chunk, head): recompute q,k,v,P,
+//                   all six attention GEMM gradients, per-head weight grads in registers
+//   block_bwd_ln1   sum of the per-head d(LN1 out) partials, LN1 backward, residual
+//   tokenize_bwd    grads of the patch embedding, its two LayerNorms, position table and mask token
+//   reduce_slabs    deterministic reduction of the per-workgroup partial-gradient slabs
+#include "msst_dev.h"
+#include "msst_kernels.h"
+
+namespace msst {
+
+// ==========================================================================================
+// head backward.  Forward (vit_simmim_original.py:314-338): pred[b,k] = W_c enc[b, idx[b,k]] + b_c,
+// loss = sum |pred - target| * gscale.  dpred holds sign(pred - target).
+// grid (S, nchunk), 384 threads = 4 token groups x 96 features.
+// ==========================================================================================
+__global__ __launch_bounds__(384) void head_bwd_kernel(HeadBwdArgs a) {
+    __shared__ float gsh[64][17];
+    __shared__ float red[4][16][96];
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int qg = tid / 96, d = tid - qg * 96;
+    const int P = a.P, N = a.N, T = a.T, K = a.K;
+    const int wc = a.per_block ? c : 0;
+    float Wreg[16], accW[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { Wreg[p] = p < P ? a.w_pix[((long)wc * P + p) * 96 + d] : 0.f; accW[p] = 0.f; }
+    float accB = 0.f;
+    const float gs = a.gout ? a.gscale * a.gout[0] : a.gscale;
+    for (int b = chunk; b < a.B; b += gridDim.y) {
+        for (int i = tid; i < N * P; i += 384) {
+            const int n = i / P, p = i - n * P;
+            const int t = c * N + n;
+            const int e0 = a.csr_ptr[(long)b * (T + 1) + t], e1 = a.csr_ptr[(long)b * (T + 1) + t + 1];
+            float s = 0.f;
+            for (int e = e0; e < e1; ++e) s += a.dpred[((long)b * K + a.csr_pos[(long)b * K + e]) * P + p];
+            gsh[n][p] = s * gs;
+        }
+        __syncthreads();
+        if (tid < P) for (int n = 0; n < N; ++n) accB += gsh[n][tid];
+        for (int n = qg; n < N; n += 4) {
+            const long off = ((long)b * T + c * N + n) * 96 + d;
+            const float yv = a.y[off];
+            float dyv = 0.f;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) {
+                if (p < P) { const float gp = gsh[n][p]; dyv += gp * Wreg[p]; accW[p] += gp * yv; }
+            }
+            a.dy[off] = dyv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int p = 0; p < 16; ++p) red[qg][p][d] = accW[p];
+    __syncthreads();
+    float* slab = a.slab + ((long)c * gridDim.y + chunk) * (P * 96 + P);
+    if (qg == 0) {
+        for (int p = 0; p < P; ++p) slab[p * 96 + d] = (red[0][p][d] + red[1][p][d]) + (red[2][p][d] + red[3][p][d]);
+    }
+    if (tid < P) slab[P * 96 + tid] = accB;
 }
+
+// ==========================================================================================
+// reduce_slabs: out[bt][i] (+)= sum_s slab[bt*batch_stride + s*slab_stride + i]
+// ==========================================================================================
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slab, long batch_stride, int nslab,
+                                                           long slab_stride, float* out, long out_batch_stride,
+                                                           int n, int accumulate) {
+    const int bt = blockIdx.y;
+    const float* src = slab + (long)bt * batch_stride;
+    float* dst = out + (long)bt * out_batch_stride;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslab; ++k) s += src[(long)k * slab_stride + i];
+        dst[i] = accumulate ? dst[i] + s : s;
+    }
+}
+
+// ==========================================================================================
+// MLP half of a block, backward.  y = x1 + W2 gelu(W1 LN2(x1) + b1) + b2
+// (vit_spatial_spectral.py:32-44, :22-29, :103).  Contiguous 64-token tiles, persistent grid.
+// Phase 1 (wave <-> 16 rows): recompute, dh, dh_pre, d(LN2 out), LN2 backward, dx1 store.
+// Phase 2 (wave <-> 16 output rows of each weight-grad): dW1 += dhp^T xn2, dW2 += dy^T h over the
+// 64 rows of the tile; bias grads as LDS column sums.
+// ==========================================================================================
+template <class P>
+struct MlpBwdSmem {
+    typedef typename P::elem elem;
+    static constexpr int LDX = 96 + P::PADE;
+    static constexpr int LDH = 64 + P::PADE;
+    elem xn2[64][LDX];
+    elem dy[64][LDX];
+    elem h[64][LDH];
+    elem dhp[64][LDH];
+};
+
+template <class P>
+__global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
+    typedef typename P::elem elem;
+    typedef typename P::frag frag;
+    typedef MlpBwdSmem<P> SM;
+    constexpr int KS = P::KS, LDX = SM::LDX, LDH = SM::LDH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
+    const elem* w1T = reinterpret_cast<const elem*>(a.w.w1T);
+    const elem* w2T = reinterpret_cast<const elem*>(a.w.w2T);
+
+    f32x4 dW1[6], dW2[6];   // dW1: C[i = n in tile wave][j = m tile jt]; dW2: C[i = m tile it][j = n in tile wave]
+    float dgam[6][4], dbet[6][4];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        dW1[i] = zero4(); dW2[i] = zero4();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { dgam[i][r] = 0.f; dbet[i][r] = 0.f; }
+    }
+    float dbias = 0.f;  // tid < 96: db2[tid]; 96 <= tid < 160: db1[tid - 96]
+
+    const int ntiles = (a.ntok + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long tok = (long)tile * 64 + wave * 16 + c;
+        const bool valid = tok < a.ntok;
+        float xhat[6][4], dyv[6][4];
+        float s1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 xr = zero4(), dr = zero4();
+            if (valid) {
+                xr = *reinterpret_cast<const f32x4*>(a.x1 + tok * 96 + m0);
+                dr = *reinterpret_cast<const f32x4*>(a.dy + tok * 96 + m0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { xhat[mt][r] = xr[r]; dyv[mt][r] = dr[r]; s1 += xr[r]; }
+            P::st_nat(&sm.dy[wave * 16][mt * 16], LDX, dr);
+        }
+        s1 = colgroup_sum(s1);
+        const float mean = s1 * (1.f / 96.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float dd = xhat[mt][r] - mean; vs += dd * dd; }
+        vs = colgroup_sum(vs);
+        const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 n4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xhat[mt][r] = (xhat[mt][r] - mean) * rstd;
+                n4[r] = xhat[mt][r] * a.w.ln2_g[m0 + r] + a.w.ln2_b[m0 + r];
+            }
+            P::st_nat(&sm.xn2[wave * 16][mt * 16], LDX, n4);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // h_pre = W1 xn2 + b1, dh = W2^T dy   (C[i = n][j = row])
+        f32x4 hp[4], dh[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) { hp[nt] = zero4(); dh[nt] = zero4(); }
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 96; k0 += KS) {
+            const frag xb = P::ld_kc(&sm.xn2[wave * 16][k0], LDX);
+            const frag db = P::ld_kc(&sm.dy[wave * 16][k0], LDX);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                hp[nt] = P::mma(P::ld_kc(w1 + (long)(nt * 16) * 96 + k0, 96), xb, hp[nt]);
+                dh[nt] = P::mma(P::ld_kc(w2T + (long)(nt * 16) * 96 + k0, 96), db, dh[nt]);
+            }
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = nt * 16 + 4 * g;
+            f32x4 hv, dv;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pre = hp[nt][r] + a.w.b1[n0 + r];
+                hv[r] = gelu_erf(pre);
+                dv[r] = dh[nt][r] * gelu_erf_grad(pre);
+            }
+            P::st_nat(&sm.h[wave * 16][nt * 16], LDH, hv);
+            P::st_nat(&sm.dhp[wave * 16][nt * 16], LDH, dv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // d(xn2) = W1^T dh_pre   (C[i = m][j = row])
+        f32x4 dxn[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) dxn[mt] = zero4();
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 64; k0 += KS) {
+            const frag hb = P::ld_kc(&sm.dhp[wave * 16][k0], LDH);
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(P::ld_kc(w1T + (long)(mt * 16) * 64 + k0, 64), hb, dxn[mt]);
+        }
+        // LN2 backward + residual
+        float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dn = dxn[mt][r];
+                dgam[mt][r] += dn * xhat[mt][r];
+                dbet[mt][r] += dn;
+                const float dg = dn * a.w.ln2_g[m0 + r];
+                dxn[mt][r] = dg;
+                g1 += dg;
+                g2 += dg * xhat[mt][r];
+            }
+        }
+        g1 = colgroup_sum(g1) * (1.f / 96.f);
+        g2 = colgroup_sum(g2) * (1.f / 96.f);
+        if (valid) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int m0 = mt * 16 + 4 * g;
+                f32x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = dyv[mt][r] + rstd * (dxn[mt][r] - g1 - xhat[mt][r] * g2);
+                *reinterpret_cast<f32x4*>(a.dx1 + tok * 96 + m0) = o4;
+            }
+        }
+        __syncthreads();
+        // ---------------- phase 2: weight grads over the 64 rows of the tile ----------------
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 64; k0 += KS) {
+            const frag ah = P::ld_ks(&sm.dhp[k0][wave * 16], LDH);  // A[i = n][k = row]
+            const frag bh = P::ld_ks(&sm.h[k0][wave * 16], LDH);    // B[j = n][k = row]
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                dW1[t] = P::mma(ah, P::ld_ks(&sm.xn2[k0][t * 16], LDX), dW1[t]);  // C[i = n][j = m]
+                dW2[t] = P::mma(P::ld_ks(&sm.dy[k0][t * 16], LDX), bh, dW2[t]);   // C[i = m][j = n]
+            }
+        }
+        if (tid < 96) {
+            float s = 0.f;
+            for (int r = 0; r < 64; ++r) s += P::up(sm.dy[r][tid]);
+            dbias += s;
+        } else if (tid < 160) {
+            float s = 0.f;
+            for (int r = 0; r < 64; ++r) s += P::up(sm.dhp[r][tid - 96]);
+            dbias += s;
+        }
+        __syncthreads();
+    }
+
+    // ---------------- write this workgroup's slab ----------------
+    float* slab = a.slab + (long)blockIdx.x * MSST_MLP_SLAB_N;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            slab[(wave * 16 + 4 * g + r) * 96 + t * 16 + c] = dW1[t][r];          // dW1[n][m]
+            slab[6144 + (t * 16 + 4 * g + r) * 64 + wave * 16 + c] = dW2[t][r];   // dW2[m][n]
+        }
+    if (tid < 96) slab[12288 + 64 + tid] = dbias;           // db2
+    else if (tid < 160) slab[12288 + tid - 96] = dbias;     // db1
+    // LN2 gamma/beta: sum over the 16 rows of the wave, then over waves through LDS
+    float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][2][96]
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = rowgroup_sum(dgam[mt][r]);
+            const float sb = rowgroup_sum(dbet[mt][r]);
+            if (c == 0) {
+                red[(wave * 2 + 0) * 96 + mt * 16 + 4 * g + r] = sg;
+                red[(wave * 2 + 1) * 96 + mt * 16 + 4 * g + r] = sb;
+            }
+        }
+    __syncthreads();
+    if (tid < 192) {
+        const int which = tid / 96, m = tid - which * 96;
+        slab[12288 + 160 + which * 96 + m] = (red[(0 * 2 + which) * 96 + m] + red[(1 * 2 + which) * 96 + m]) +
+                                             (red[(2 * 2 + which) * 96 + m] + red[(3 * 2 + which) * 96 + m]);
+    }
+}
+
+template __global__ void block_bwd_mlp_kernel<PF32>(MlpBwdArgs);
+template __global__ void block_bwd_mlp_kernel<PBF16>(MlpBwdArgs);
+
+// ==========================================================================================
+// attention half of a block, backward (vit_spatial_spectral.py:47-78 under PreNorm :22-29).
+// grid (nchunk, H): workgroup (chunk, h) walks the 64-row tiles chunk, chunk+nchunk, ... for ONE
+// head, so that the head's weight gradients (dWq|dWk|dWv [3][64][96], dWout_h [96][64]) stay in
+// registers (96 per lane) for the whole walk and are written once as a slab.
+// Per tile: LN1(x) -> q,k,v^T -> S^T,P -> O;  dO = da Wout_h;  dP -> dS;  dV, dQ, dK;  weight grads;
+// the head's partial d(LN1 out) = [dq|dk|dv] Wqkv_h is stored for block_bwd_ln1 to sum over heads.
+// LDS holds every intermediate once; operands needed in the other orientation are fetched with
+// k-strided fragment loads (ds_read_b64_tr_b16 in bf16).  xd holds LN1(x), then da, then LN1(x) again.
+// ==========================================================================================
+template <class P>
+struct AttnBwdSmem {
+    typedef typename P::elem elem;
+    static constexpr int LDX = 96 + P::PADE;
+    static constexpr int LDH = 64 + P::PADE;
+    elem xd[64][LDX];
+    elem q[64][LDH];    // q[row][d]   -> later dq[row][d]
+    elem k[64][LDH];    // k[row][d]   -> later dk[row][d]
+    elem vt[64][LDH];   // vt[d][row]  -> later dv[row][d]
+    elem p[64][LDH];    // p[query][key]
+    elem dO[64][LDH];   // dO[query][d]
+    elem ds[64][LDH];   // ds[query][key]
+    elem o[64][LDH];    // o[query][d]
+};
+
+template <class P>
+__device__ __forceinline__ void ln1_rows_to_lds(const float* x, const float* gam, const float* bet, const TileMap& tm,
+                                                int tile, typename P::elem (*dst)[96 + P::PADE]) {
+    const int tid = threadIdx.x;
+    const int r = tid >> 2, part = tid & 3;
+    const long tok = tm.token(tile, r);
+    float v[24];
+    if (tok >= 0) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x + tok * 96 + part * 24);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) v[i] = 0.f;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) s += v[i];
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s * (1.f / 96.f);
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+    vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+    const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        const int d = part * 24 + i;
+        dst[r][d] = P::cvt((v[i] - mean) * rstd * gam[d] + bet[d]);
+    }
+}
+
+template <class P>
+__global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
+    typedef typename P::elem elem;
+    typedef typename P::frag frag;
+    typedef AttnBwdSmem<P> SM;
+    constexpr int KS = P::KS, LDX = SM::LDX, LDH = SM::LDH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int H = a.H, inner = H * 64, h = blockIdx.y;
+    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
+    const elem* wqkvT = reinterpret_cast<const elem*>(a.w.wqkvT);
+    const elem* woutT = reinterpret_cast<const elem*>(a.w.woutT);
+    const TileMap tm = a.tm;
+    const int L = tm.L;
+    elem* part = reinterpret_cast<elem*>(a.dxn_part) + (long)h * a.ntok * 96;
+
+    // persistent weight-grad accumulators: dWqkv: C[i = d in tile wave][j = m tile], for q,k,v;
+    // dWout: C[i = m tile][j = d in tile wave]
+    f32x4 gq[6], gk[6], gv[6], go[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { gq[i] = zero4(); gk[i] = zero4(); gv[i] = zero4(); go[i] = zero4(); }
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tm, tile, sm.xd);
+        __syncthreads();
+        // ---------------- phase A: q, k, v^T (wave <-> 16 head channels) ----------------
+        {
+            f32x4 cq[4], ck[4], cv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
+            const elem* wq = wqkv + (long)((0 * H + h) * 64 + wave * 16) * 96;
+            const elem* wk = wqkv + (long)((1 * H + h) * 64 + wave * 16) * 96;
+            const elem* wv = wqkv + (long)((2 * H + h) * 64 + wave * 16) * 96;
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 96; k0 += KS) {
+                const frag aq = P::ld_kc(wq + k0, 96);
+                const frag ak = P::ld_kc(wk + k0, 96);
+                const frag av = P::ld_kc(wv + k0, 96);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const frag xb = P::ld_kc(&sm.xd[t * 16][k0], LDX);
+                    cq[t] = P::mma(aq, xb, cq[t]);
+                    ck[t] = P::mma(ak, xb, ck[t]);
+                    cv[t] = P::mma(xb, av, cv[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                P::st_nat(&sm.q[t * 16][wave * 16], LDH, cq[t]);
+                P::st_nat(&sm.k[t * 16][wave * 16], LDH, ck[t]);
+                P::st_nat(&sm.vt[wave * 16][t * 16], LDH, cv[t]);
+            }
+        }
+        __syncthreads();
+        // ---------------- da rows -> xd (overwrites LN1(x); rows of this wave only) ----------------
+        {
+            const int r = tid >> 2, pt = tid & 3;
+            const long tok = tm.token(tile, r);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 t4 = zero4();
+                if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sm.xd[r][pt * 24 + 4 * i + e] = P::cvt(t4[e]);
+            }
+        }
+        // ---------------- phase B: wave <-> 16 query rows ----------------
+        f32x4 pr[4];
+        {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) pr[t] = zero4();
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                const frag qb = P::ld_kc(&sm.q[wave * 16][k0], LDH);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pr[t] = P::mma(P::ld_kc(&sm.k[t * 16][k0], LDH), qb, pr[t]);  // C[i = key][j = query]
+            }
+            const int qseq = (wave * 16 + c) / L;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    const float v = (key / L == qseq) ? pr[t][r] * a.scale : -INFINITY;
+                    pr[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = colgroup_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = expf(pr[t][r] - mx); pr[t][r] = e; sum += e; }
+            sum = colgroup_sum(sum);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                pr[t] = pr[t] * inv;
+                P::st_nat(&sm.p[wave * 16][t * 16], LDH, pr[t]);  // p[query][key]
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            // o = P v  (C[i = d][j = query]) and dO = Wout_h^T da (C[i = d][j = query])
+            f32x4 o[4], dov[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { o[t] = zero4(); dov[t] = zero4(); }
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                const frag pb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);
+            }
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 96; k0 += KS) {
+                const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dov[t] = P::mma(P::ld_kc(woutT + (long)(h * 64 + t * 16) * 96 + k0, 96), db, dov[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                P::st_nat(&sm.o[wave * 16][t * 16], LDH, o[t]);      // o[query][d]
+                P::st_nat(&sm.dO[wave * 16][t * 16], LDH, dov[t]);   // dO[query][d]
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            // dP^T[key][query] = sum_d v[key][d] dO[query][d]: A = v (k-strided read of vt), B = dO rows
+            f32x4 dp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dp[t] = zero4();
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                const frag db = P::ld_kc(&sm.dO[wave * 16][k0], LDH);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dp[t] = P::mma(P::ld_ks(&sm.vt[k0][t * 16], LDH), db, dp[t]);
+            }
+            float delta = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) delta += pr[t][r] * dp[t][r];
+            delta = colgroup_sum(delta);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                f32x4 d4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta) * a.scale;
+                P::st_nat(&sm.ds[wave * 16][t * 16], LDH, d4);  // ds[query][key]
+            }
+        }
+        __syncthreads();
+        // ---------------- phase C: contractions over all 64 queries / keys ----------------
+        f32x4 dq[4], dk[4], dv[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { dq[t] = zero4(); dk[t] = zero4(); dv[t] = zero4(); }
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 64; k0 += KS) {
+            // dWout_h[m][d] += sum_q da[q][m] o[q][d]      C[i = m tile t][j = d tile wave]
+            const frag ob = P::ld_ks(&sm.o[k0][wave * 16], LDH);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) go[t] = P::mma(P::ld_ks(&sm.xd[k0][t * 16], LDX), ob, go[t]);
+            // dv[key][d] = sum_q p[q][key] dO[q][d]         C[i = d tile t][j = key tile wave]
+            const frag pb = P::ld_ks(&sm.p[k0][wave * 16], LDH);
+            // dk[key][d] = sum_q ds[q][key] q[q][d]         C[i = d tile t][j = key tile wave]
+            const frag sb = P::ld_ks(&sm.ds[k0][wave * 16], LDH);
+            // dq[query][d] = sum_key ds[query][key] k[key][d]   C[i = d tile t][j = query tile wave]
+            const frag sq = P::ld_kc(&sm.ds[wave * 16][k0], LDH);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                dv[t] = P::mma(P::ld_ks(&sm.dO[k0][t * 16], LDH), pb, dv[t]);
+                dk[t] = P::mma(P::ld_ks(&sm.q[k0][t * 16], LDH), sb, dk[t]);
+                dq[t] = P::mma(P::ld_ks(&sm.k[k0][t * 16], LDH), sq, dq[t]);
+            }
+        }
+        __syncthreads();
+        // dq / dk / dv over the dead q / k / vt buffers, all as [row][d]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            P::st_nat(&sm.q[wave * 16][t * 16], LDH, dq[t]);
+            P::st_nat(&sm.k[wave * 16][t * 16], LDH, dk[t]);
+            P::st_nat(&sm.vt[wave * 16][t * 16], LDH, dv[t]);
+        }
+        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tm, tile, sm.xd);
+        __syncthreads();
+        // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
+#pragma unroll P::UNROLL
+        for (int k0 = 0; k0 < 64; k0 += KS) {
+            // dW{q,k,v}[d][m] += sum_row d{q,k,v}[row][d] xn[row][m]    C[i = d tile wave][j = m tile t]
+            const frag aq = P::ld_ks(&sm.q[k0][wave * 16], LDH);
+            const frag ak = P::ld_ks(&sm.k[k0][wave * 16], LDH);
+            const frag av = P::ld_ks(&sm.vt[k0][wave * 16], LDH);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const frag xb = P::ld_ks(&sm.xd[k0][t * 16], LDX);
+                gq[t] = P::mma(aq, xb, gq[t]);
+                gk[t] = P::mma(ak, xb, gk[t]);
+                gv[t] = P::mma(av, xb, gv[t]);
+            }
+        }
+        {
+            // dxn_h[row][m] = sum_d dq Wq + dk Wk + dv Wv         C[i = m tile t][j = row tile wave]
+            f32x4 dx[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) dx[t] = zero4();
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                const frag bq = P::ld_kc(&sm.q[wave * 16][k0], LDH);
+                const frag bk = P::ld_kc(&sm.k[wave * 16][k0], LDH);
+                const frag bv = P::ld_kc(&sm.vt[wave * 16][k0], LDH);
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const elem* wt = wqkvT + (long)(t * 16) * (3 * inner) + h * 64 + k0;
+                    dx[t] = P::mma(P::ld_kc(wt, 3 * inner), bq, dx[t]);
+                    dx[t] = P::mma(P::ld_kc(wt + inner, 3 * inner), bk, dx[t]);
+                    dx[t] = P::mma(P::ld_kc(wt + 2 * inner, 3 * inner), bv, dx[t]);
+                }
+            }
+            const long tok = tm.token(tile, wave * 16 + c);
+            if (tok >= 0) {
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    elem* dst = part + tok * 96 + t * 16 + 4 * g;
+                    if constexpr (sizeof(elem) == 4) {
+                        *reinterpret_cast<f32x4*>(dst) = dx[t];
+                    } else {
+                        s16x4 v4;
+                        v4[0] = (short)f2bf(dx[t][0]); v4[1] = (short)f2bf(dx[t][1]);
+                        v4[2] = (short)f2bf(dx[t][2]); v4[3] = (short)f2bf(dx[t][3]);
+                        *reinterpret_cast<s16x4*>(dst) = v4;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---------------- slab: [dWq | dWk | dWv] [3][64][96], dWout_h [96][64] ----------------
+    float* slab = a.slab + ((long)blockIdx.x * H + h) * MSST_ATTN_SLAB_N;
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int d = wave * 16 + 4 * g + r, m = t * 16 + c;
+            slab[0 * 6144 + d * 96 + m] = gq[t][r];
+            slab[1 * 6144 + d * 96 + m] = gk[t][r];
+            slab[2 * 6144 + d * 96 + m] = gv[t][r];
+            slab[3 * 6144 + (t * 16 + 4 * g + r) * 64 + wave * 16 + c] = go[t][r];  // dWout_h[m][d]
+        }
+}
+
+template __global__ void block_bwd_attn_kernel<PF32>(AttnBwdArgs);
+template __global__ void block_bwd_attn_kernel<PBF16>(AttnBwdArgs);
+
+// scatter-reduce of the attention slabs into to_qkv.weight.grad [3*H*64][96] and to_out.0.weight.grad
+// [96][H*64]:  slab[chunk][h][...] summed over chunks.
+__global__ __launch_bounds__(256) void attn_slab_reduce_kernel(const float* slab, int nchunk, int H, float* dwqkv,
+                                                               float* dwout) {
+    const int h = blockIdx.y;
+    const int inner = H * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < MSST_ATTN_SLAB_N; i += gridDim.x * 256) {
+        float s = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) s += slab[((long)ch * H + h) * MSST_ATTN_SLAB_N + i];
+        if (i < 3 * 6144) {
+            const int which = i / 6144, rem = i - which * 6144;  // rem = d*96 + m
+            dwqkv[((long)(which * H + h) * 64) * 96 + rem] = s;
+        } else {
+            const int rem = i - 3 * 6144, m = rem / 64, d = rem - m * 64;
+            dwout[(long)m * inner + h * 64 + d] = s;
+        }
+    }
+}
+
+// ==========================================================================================
+// LN1 backward + residual:  dx = dx1 + LN1_bwd(sum_h part[h]; x)   (vit_spatial_spectral.py:22-29,:102)
+// persistent grid over 64-token tiles; 4 threads per row, 24 features each.
+// ==========================================================================================
+template <class E>
+__global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
+    __shared__ float red[64][97];
+    const int tid = threadIdx.x, r = tid >> 2, part = tid & 3;
+    const E* parts = reinterpret_cast<const E*>(a.dxn_part);
+    float dg[24], db[24], dbo[24], gam[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { dg[i] = 0.f; db[i] = 0.f; dbo[i] = 0.f; gam[i] = a.ln1_g[part * 24 + i]; }
+    const int ntiles = (a.ntok + 63) / 64;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long tok = (long)tile * 64 + r;
+        if (tok < a.ntok) {   // the 4 threads of a row are in/out together
+            float v[24], dn[24];
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
+#pragma unroll
+            for (int i = 0; i < 24; ++i) dn[i] = 0.f;
+            for (int h = 0; h < a.H; ++h) {
+                const E* p = parts + ((long)h * a.ntok + tok) * 96 + part * 24;
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    if constexpr (sizeof(E) == 4) dn[i] += p[i]; else dn[i] += bf2f(p[i]);
+                }
+            }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) s += v[i];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            const float mean = s * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+            float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const float xh = (v[i] - mean) * rstd;
+                v[i] = xh;
+                dg[i] += dn[i] * xh;
+                db[i] += dn[i];
+                dn[i] *= gam[i];
+                g1 += dn[i];
+                g2 += dn[i] * xh;
+            }
+            g1 += __shfl_xor(g1, 1); g1 += __shfl_xor(g1, 2);
+            g2 += __shfl_xor(g2, 1); g2 += __shfl_xor(g2, 2);
+            g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
+            const f32x4* d1 = reinterpret_cast<const f32x4*>(a.dx1 + tok * 96 + part * 24);
+            f32x4* dst = reinterpret_cast<f32x4*>(a.dx + tok * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 t4 = d1[i], o4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o4[e] = t4[e] + rstd * (dn[4*i+e] - g1 - v[4*i+e] * g2);
+                    dbo[4*i+e] += t4[e];   // to_out bias grad = column sum of d(attention output) = dx1
+                }
+                dst[i] = o4;
+            }
+        }
+    }
+    // reduce dgamma / dbeta / d(to_out bias) over the 64 row-threads
+    float* slab = a.slab + (long)blockIdx.x * 288;
+    for (int which = 0; which < 3; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 24; ++i) red[r][part * 24 + i] = which == 0 ? dg[i] : which == 1 ? db[i] : dbo[i];
+        __syncthreads();
+        if (tid < 96) {
+            float s = 0.f;
+            for (int rr = 0; rr < 64; ++rr) s += red[rr][tid];
+            slab[which * 96 + tid] = s;
+        }
+    }
+}
+
+// ==========================================================================================
+// tokenizer backward (forward: tokenize_fwd_kernel).  grid (S, nchunk), 256 threads.
+// slab per (c, chunk): [dpos N*96 | dW 96*P | db 96 | dpost_g 96 | dpost_b 96 | dmask 96 | dpre_g 16 | dpre_b 16]
+// ==========================================================================================
+__global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
+    __shared__ float patch[16][64];
+    __shared__ float W[96][17];
+    __shared__ float de_s[64][97];
+    __shared__ float xn_s[64][17];
+    __shared__ float bias[96];
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
+    const int P = a.P, N = a.N, T = a.T;
+    for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
+    if (tid < 96) bias[tid] = a.b_emb[c * 96 + tid];
+    const int n = tid >> 2, part = tid & 3;
+    const bool active = n < N;
+    float dpos[24], dmask[24], dpg[24], dpb[24], dbc[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { dpos[i] = 0.f; dmask[i] = 0.f; dpg[i] = 0.f; dpb[i] = 0.f; dbc[i] = 0.f; }
+    float dpre_g[16], dpre_b[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { dpre_g[k] = 0.f; dpre_b[k] = 0.f; }
+    // dW accumulators: thread owns pairs (d, k) = linear index tid + 256*j < 96*P
+    float dWacc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) dWacc[j] = 0.f;
+
+    for (int b = chunk; b < a.B; b += gridDim.y) {
+        __syncthreads();
+        const float* src = a.img + ((long)b * a.S + c) * P * N;
+        for (int i = tid; i < P * N; i += 256) patch[i / N][i % N] = src[i];
+        __syncthreads();
+        if (active) {
+            const int t = c * N + n;
+            const bool masked = a.mask[(long)b * T + t] != 0;
+            float dt[24];
+            const f32x4* dsrc = reinterpret_cast<const f32x4*>(a.dx0 + ((long)b * T + t) * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { f32x4 t4 = dsrc[i]; dt[4*i] = t4[0]; dt[4*i+1] = t4[1]; dt[4*i+2] = t4[2]; dt[4*i+3] = t4[3]; }
+#pragma unroll
+            for (int i = 0; i < 24; ++i) dpos[i] += dt[i];
+            // recompute
+            float xh0[16], xn[16];
+            float mean = 0.f;
+            for (int k = 0; k < P; ++k) mean += patch[k][n];
+            mean /= P;
+            float var = 0.f;
+            for (int k = 0; k < P; ++k) { const float d = patch[k][n] - mean; var += d * d; }
+            const float rstd = rsqrtf(var / P + 1e-5f);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                if (k < P) { xh0[k] = (patch[k][n] - mean) * rstd; xn[k] = xh0[k] * a.pre_g[k] + a.pre_b[k]; }
+                else { xh0[k] = 0.f; xn[k] = 0.f; }
+            }
+            float e[24];
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int d = part * 24 + i;
+                float acc = bias[d];
+                for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
+                e[i] = acc;
+                s += acc;
+            }
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            const float m2 = s * (1.f / 96.f);
+            float v2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = e[i] - m2; v2 += d * d; }
+            v2 += __shfl_xor(v2, 1); v2 += __shfl_xor(v2, 2);
+            const float rstd2 = rsqrtf(v2 * (1.f / 96.f) + 1e-5f);
+            // masked tokens: gradient goes to the mask token only (and the position table, above)
+            float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int d = part * 24 + i;
+                const float eh = (e[i] - m2) * rstd2;
+                e[i] = eh;
+                if (masked) { dmask[i] += dt[i]; dt[i] = 0.f; }
+                dpg[i] += dt[i] * eh;
+                dpb[i] += dt[i];
+                dt[i] *= a.post_g[d];
+                g1 += dt[i];
+                g2 += dt[i] * eh;
+            }
+            g1 += __shfl_xor(g1, 1); g1 += __shfl_xor(g1, 2);
+            g2 += __shfl_xor(g2, 1); g2 += __shfl_xor(g2, 2);
+            g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
+            float dxn[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) dxn[k] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) {
+                const int d = part * 24 + i;
+                const float de = rstd2 * (dt[i] - g1 - e[i] * g2);
+                dbc[i] += de;
+                de_s[n][d] = de;
+                for (int k = 0; k < P; ++k) dxn[k] += W[d][k] * de;
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                float v = dxn[k];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+                if (part == 0 && k < P) { dpre_g[k] += v * xh0[k]; dpre_b[k] += v; xn_s[n][k] = xn[k]; }
+            }
+        }
+        __syncthreads();
+        // dW[d][k] += sum_n de[n][d] * xn[n][k]
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < 96 * P) {
+                const int d = idx / P, k = idx - d * P;
+                float s = 0.f;
+                for (int nn = 0; nn < N; ++nn) s += de_s[nn][d] * xn_s[nn][k];
+                dWacc[j] += s;
+            }
+        }
+    }
+    // ---------------- slab ----------------
+    const int slab_n = N * 96 + 96 * P + 96 * 4 + 32;
+    float* slab = a.slab + ((long)c * gridDim.y + chunk) * slab_n;
+    if (active) {
+#pragma unroll
+        for (int i = 0; i < 24; ++i) slab[n * 96 + part * 24 + i] = dpos[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < 96 * P) slab[N * 96 + idx] = dWacc[j];
+    }
+    float* vec = slab + N * 96 + 96 * P;
+    for (int which = 0; which < 4; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const float v = which == 0 ? dbc[i] : which == 1 ? dpg[i] : which == 2 ? dpb[i] : dmask[i];
+            de_s[n][part * 24 + i] = active ? v : 0.f;
+        }
+        __syncthreads();
+        if (tid < 96) {
+            float s = 0.f;
+            for (int rr = 0; rr < 64; ++rr) s += de_s[rr][tid];
+            vec[which * 96 + tid] = s;
+        }
+    }
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { de_s[n][k] = active ? dpre_g[k] : 0.f; de_s[n][16 + k] = active ? dpre_b[k] : 0.f; }
+    }
+    __syncthreads();
+    if (tid < 32) {
+        float s = 0.f;
+        for (int rr = 0; rr < 64; ++rr) s += de_s[rr][tid];
+        vec[4 * 96 + tid] = s;
+    }
+}
+
+// position-table gradient for the factorised (spectral_pos_embed) table:
+// dpos_embed[n][0:split] = sum_c dpos[c][n][0:split]; dchannel_embed[c][0:96-split] = sum_n dpos[c][n][split:96]
+__global__ __launch_bounds__(256) void pos_split_kernel(const float* dpos /*[S][N][96]*/, int S, int N, int split,
+                                                        float* dpe, float* dce) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int npe = N * split, nce = S * (96 - split);
+    if (i < npe) {
+        const int n = i / split, d = i - n * split;
+        float s = 0.f;
+        for (int c = 0; c < S; ++c) s += dpos[((long)c * N + n) * 96 + d];
+        dpe[i] = s;
+    } else if (i < npe + nce) {
+        const int j = i - npe, c = j / (96 - split), d = j - c * (96 - split);
+        float s = 0.f;
+        for (int n = 0; n < N; ++n) s += dpos[((long)c * N + n) * 96 + split + d];
+        dce[j] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st) {
+    if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(a.S, nchunk), dim3(384), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_reduce_slabs(const float* slab, int nbatch, long batch_stride, int nslab, long slab_stride, float* out,
+                        long out_batch_stride, int n, int accumulate, hipStream_t st) {
+    if (n <= 0 || nbatch <= 0) return 0;
+    int gx = (n + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, nbatch), dim3(256), 0, st, slab, batch_stride, nslab, slab_stride,
+                       out, out_batch_stride, n, accumulate);
+    return (int)hipGetLastError();
+}
+
+template <class K>
+static int set_smem(K kernel, size_t smem, bool& done) {
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        done = true;
+    }
+    return 0;
+}
+
+int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st) {
+    static bool d0 = false, d1 = false;
+    if (prec == MSST_PREC_F32) {
+        const size_t smem = sizeof(MlpBwdSmem<PF32>);
+        int rc = set_smem(&block_bwd_mlp_kernel<PF32>, smem, d0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(block_bwd_mlp_kernel<PF32>, dim3(grid), dim3(256), smem, st, a);
+    } else {
+        const size_t smem = sizeof(MlpBwdSmem<PBF16>);
+        int rc = set_smem(&block_bwd_mlp_kernel<PBF16>, smem, d1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(block_bwd_mlp_kernel<PBF16>, dim3(grid), dim3(256), smem, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st) {
+    static bool d0 = false, d1 = false;
+    if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
+    dim3 grid(nchunk, a.H);
+    if (prec == MSST_PREC_F32) {
+        const size_t smem = sizeof(AttnBwdSmem<PF32>);
+        int rc = set_smem(&block_bwd_attn_kernel<PF32>, smem, d0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
+    } else {
+        const size_t smem = sizeof(AttnBwdSmem<PBF16>);
+        int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(block_bwd_attn_kernel<PBF16>, grid, dim3(256), smem, st, a);
+    }
+    return (int)hipGetLastError();
+}
+
+int launch_attn_slab_reduce(const float* slab, int nchunk, int H, float* dwqkv, float* dwout, hipStream_t st) {
+    hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(24, H), dim3(256), 0, st, slab, nchunk, H, dwqkv, dwout);
+    return (int)hipGetLastError();
+}
+
+int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st) {
+    if (prec == MSST_PREC_F32) hipLaunchKernelGGL(block_bwd_ln1_kernel<float>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(block_bwd_ln1_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st) {
+    if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(tokenize_bwd_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    return (int)hipGetLastError();
+}
+
+int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st) {
+    const int n = N * split + S * (96 - split);
+    hipLaunchKernelGGL(pos_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dpos, S, N, split, dpe, dce);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst

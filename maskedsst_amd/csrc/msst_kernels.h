@@ -62,7 +62,55 @@ struct HeadArgs {
     int B, S, N, T, P, K, per_block;
 };
 
+struct HeadBwdArgs {
+    const float* y; const float* dpred; const int* csr_ptr; const int* csr_pos; const float* w_pix;
+    float* dy; float* slab; float gscale;
+    const float* gout;   // optional device scalar: d(final)/d(loss), multiplied into gscale
+    int B, S, N, T, P, K, per_block;
+};
+
+#define MSST_MLP_SLAB_N (64 * 96 + 96 * 64 + 64 + 96 + 96 + 96)
+#define MSST_ATTN_SLAB_N (3 * 64 * 96 + 96 * 64)
+
+struct MlpBwdArgs {
+    BlockWeights w;
+    const float* x1; const float* dy; float* dx1; float* slab;
+    long ntok;
+};
+
+struct AttnBwdArgs {
+    BlockWeights w;
+    const float* x; const float* da; void* dxn_part; float* slab;
+    TileMap tm;
+    int ntiles, H;
+    long ntok;
+    float scale;
+};
+
+struct Ln1BwdArgs {
+    const float* x; const float* dx1; const void* dxn_part; const float* ln1_g; float* dx; float* slab;
+    long ntok;
+    int H;
+};
+
+struct TokBwdArgs {
+    const float* img; const float* pre_g; const float* pre_b; const float* w_emb; const float* b_emb;
+    const float* post_g; const float* post_b; const uint8_t* mask; const float* dx0; float* slab;
+    int B, S, N, T, P;
+};
+
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st);
+int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st);
+int launch_reduce_slabs(const float* slab, int nbatch, long batch_stride, int nslab, long slab_stride, float* out,
+                        long out_batch_stride, int n, int accumulate, hipStream_t st);
+int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
+int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st);
+int launch_attn_slab_reduce(const float* slab, int nchunk, int H, float* dwqkv, float* dwout, hipStream_t st);
+int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);
+int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st);
+int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st);
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                 float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st);
 

@@ -1,0 +1,62 @@
+// Fused AdamW over the flat parameter buffer (one launch for all ~350 parameter tensors).
+// Semantics of torch.optim.AdamW as configured by the reference (src/utils.py:36-45; pretrain.py:69):
+//   g' = clamp(g * gscale, -clamp, clamp)      (pretrain.py:71-73 value clamp; gscale = 1/world for DP mean)
+//   p  = p * (1 - lr*wd);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
+//   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "msst_dev.h"
+#include "msst_kernels.h"
+#include <math.h>
+
+namespace msst {
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                                    float b1, float b2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                    float clampv, float gscale) {
+    const long n4 = n >> 2;
+    f32x4* p4 = reinterpret_cast<f32x4*>(p);
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    f32x4* m4 = reinterpret_cast<f32x4*>(m);
+    f32x4* v4 = reinterpret_cast<f32x4*>(v);
+    const float step_size = lr / bc1;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 pp = p4[i], gg = g4[i], mm = m4[i], vv = v4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gr = gg[e] * gscale;
+            if (clampv > 0.f) gr = fminf(fmaxf(gr, -clampv), clampv);
+            float pv = pp[e] * (1.f - lr * wd);
+            const float mn = b1 * mm[e] + (1.f - b1) * gr;
+            const float vn = b2 * vv[e] + (1.f - b2) * gr * gr;
+            const float denom = sqrtf(vn) / bc2_sqrt + eps;
+            pv -= step_size * (mn / denom);
+            pp[e] = pv; mm[e] = mn; vv[e] = vn;
+        }
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    // tail (n not a multiple of 4)
+    for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float gr = g[i] * gscale;
+        if (clampv > 0.f) gr = fminf(fmaxf(gr, -clampv), clampv);
+        float pv = p[i] * (1.f - lr * wd);
+        const float mn = b1 * m[i] + (1.f - b1) * gr;
+        const float vn = b2 * v[i] + (1.f - b2) * gr * gr;
+        pv -= step_size * (mn / (sqrtf(vn) / bc2_sqrt + eps));
+        p[i] = pv; m[i] = mn; v[i] = vn;
+    }
+}
+
+int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
+                 float wd, int step, float clamp, float gscale, hipStream_t st) {
+    if (n <= 0) return 0;
+    const float bc1 = 1.f - powf(b1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(b2, (float)step));
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1,
+                       bc2_sqrt, clamp, gscale);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst

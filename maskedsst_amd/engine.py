@@ -11,7 +11,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import MsstBlockWeights, MsstPrepJob, PREC_BF16, PREC_F32, MODE_SPATIAL, MODE_SPECTRAL
+from ._lib import (MsstBlockWeights, MsstBlockGrads, MsstPrepJob, PREC_BF16, PREC_F32, MODE_SPATIAL,
+                   MODE_SPECTRAL, MLP_SLAB, ATTN_SLAB, LN1_SLAB)
 from .flat import FlatParams
 
 D = 96
@@ -44,6 +45,10 @@ class Engine:
         self.fp = FlatParams(encoder, mim)
         self.prec = _prec_of(getattr(encoder, "precision", None))
         self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
+        self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "512"))      # persistent grid of the row-wise bwd kernels
+        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "64"))  # x heads workgroups in the attention bwd
+        self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "16"))
+        self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self._wbuf = None
         self._jobs = None
         self._bw = None
@@ -99,6 +104,7 @@ class Engine:
         base = self._wbuf.data_ptr()
         jobs = (MsstPrepJob * (8 * len(layers)))()
         self._bw = []
+        self._bg = []
         off = 0
         j = 0
         maxel = 0
@@ -116,6 +122,10 @@ class Engine:
             for name in ("ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2"):
                 setattr(bw, name, self.fp.ptr(f"{sname}.{l}.{name}"))
             self._bw.append(bw)
+            bg = MsstBlockGrads()
+            for name in ("ln1_g", "ln1_b", "wqkv", "wout", "bo", "ln2_g", "ln2_b", "w1", "b1", "w2", "b2"):
+                setattr(bg, name, self.fp.ptr(f"{sname}.{l}.{name}", self.fp.grad))
+            self._bg.append(bg)
         raw = bytes(jobs)
         self._jobs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self._njobs = j
@@ -194,6 +204,113 @@ class Engine:
             _p(dpred), _p(pred), _p(partial), _p(loss), B, S, N, P, K, _stream()), "msst_head_fwd")
         return loss, dpred, pred
 
+    # ------------------------------------------------------------------ backward pieces
+    def _fire(self, bucket):
+        if self.bucket_hook is not None:
+            for name, start, end in self.fp.buckets:
+                if name == bucket:
+                    self.bucket_hook(name, start, end)
+
+    def head_bwd(self, y, dpred, csr_ptr, csr_pos, gout=None):
+        """-> dy [B, T, 96]; to_pixels grads land in the flat grad buffer"""
+        B, T, _ = y.shape
+        S, N, P = self.S, self.N, self.P
+        K = dpred.shape[1]
+        dev = y.device
+        nchunk = max(1, min(B, 512 // max(S, 1)))
+        dy = torch.empty_like(y)
+        slab = torch.empty(S * nchunk * (P * 96 + P), dtype=torch.float32, device=dev)
+        per_block = 1 if hasattr(self.mim.to_pixels, "layers") else 0
+        gscale = 1.0 / (B * K * P) / K
+        V = ctypes.c_void_p
+        g = self.fp.grad
+        _lib.check(self.lib.msst_head_bwd(
+            _p(y), _p(dpred), _p(csr_ptr), _p(csr_pos), V(self.fp.ptr("to_pixels.w.0")), per_block, gscale, _p(gout),
+            _p(dy), _p(slab), nchunk, V(self.fp.ptr("to_pixels.w.0", g)), V(self.fp.ptr("to_pixels.b.0", g)),
+            B, S, N, P, K, _stream()), "msst_head_bwd")
+        self._fire("head")
+        return dy
+
+    def blocks_bwd(self, acts, x1s, dy):
+        """backward through the 2*depth blocks (reverse order); returns dx0"""
+        B = dy.shape[0]
+        S, N, H = self.S, self.N, self.enc.heads
+        dev = dy.device
+        ntok = B * S * N
+        esz = 4 if self.prec == PREC_F32 else 2
+        dx1 = torch.empty(ntok * 96, dtype=torch.float32, device=dev)
+        part = torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev)
+        nslab = max(self.grid_rows * MLP_SLAB, self.attn_chunks * H * ATTN_SLAB, self.grid_rows * LN1_SLAB)
+        slab = torch.empty(nslab, dtype=torch.float32, device=dev)
+        layers = self._layers()
+        g = dy
+        other = torch.empty_like(dy)
+        for i in reversed(range(len(layers))):
+            sname, l = layers[i]
+            mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+            _lib.check(self.lib.msst_block_bwd(
+                ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
+                _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec,
+                _stream()), "msst_block_bwd")
+            g, other = other, g
+            self._fire(f"{sname}.{l}")
+        return g
+
+    def tokenize_bwd(self, img, mask_u8, dx0):
+        B = img.shape[0]
+        S, N, P = self.S, self.N, self.P
+        dev = img.device
+        nchunk = max(1, min(B, self.tok_chunks))
+        ss = N * 96 + 96 * P + 96 * 4 + 32
+        slab = torch.empty(S * nchunk * ss + S * N * 96, dtype=torch.float32, device=dev)
+        fp, g = self.fp, self.fp.grad
+        V = ctypes.c_void_p
+        if self.enc.spectral_pos_embed:
+            split = self.enc.pos_embed.shape[-1]
+            dpa, dpb = fp.ptr("pos_embed", g), fp.ptr("channel_embed", g)
+        else:
+            split = 0
+            dpa, dpb = fp.ptr("pos_embedding", g), 0
+        dmt = fp.ptr("mask_token", g) if self.mim is not None else 0
+        _lib.check(self.lib.msst_tokenize_bwd(
+            _p(img), V(fp.ptr("pre_g")), V(fp.ptr("pre_b")), V(fp.ptr("embed.w.0")), V(fp.ptr("embed.b.0")),
+            V(fp.ptr("post_g")), V(fp.ptr("post_b")), _p(mask_u8), _p(dx0), _p(slab), nchunk,
+            V(fp.ptr("pre_g", g)), V(fp.ptr("pre_b", g)), V(fp.ptr("embed.w.0", g)), V(fp.ptr("embed.b.0", g)),
+            V(fp.ptr("post_g", g)), V(fp.ptr("post_b", g)), V(dpa), V(dpb), split, V(dmt), B, S, N, P, _stream()),
+            "msst_tokenize_bwd")
+        self._fire("tokenizer")
+
+    # ------------------------------------------------------------------ autograd entry (SimMIM loss)
+    def trainable(self):
+        """[(flat name, parameter)] of everything that receives a gradient in pre-training"""
+        groups, _ = self.fp._ordered()
+        return [(n, p) for _, g in groups for n, p in g]
+
+    def simmim_loss(self, img, bool_mask, idx):
+        """scalar loss attached to autograd (reference SimMIMSpatialSpectral.forward :203-340)"""
+        self._require_cuda(img)
+        self.ensure()
+        dev = img.device
+        T = self.S * self.N
+        img = img.contiguous().float()
+        from .masking import inverse_csr
+        bm = bool_mask.cpu().numpy() if torch.is_tensor(bool_mask) else np.asarray(bool_mask)
+        ix = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
+        ptr, pos = inverse_csr(ix, T)
+        mask_u8 = torch.from_numpy(bm.astype(np.uint8)).to(dev, non_blocking=True)
+        idx32 = torch.from_numpy(ix.astype(np.int32)).to(dev, non_blocking=True)
+        csr_ptr = torch.from_numpy(ptr).to(dev, non_blocking=True)
+        csr_pos = torch.from_numpy(pos).to(dev, non_blocking=True)
+        names = [n for n, _ in self.trainable()]
+        params = [p for _, p in self.trainable()]
+        if not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
+            self.prep_weights()
+            x0 = self.tokenize(img, mask_u8)
+            acts, _ = self.blocks_fwd(x0, save=False)
+            loss, _, _ = self.head_fwd(acts[-1], img, idx32)
+            return loss
+        return _SimMIMLossFn.apply(self, names, img, mask_u8, idx32, csr_ptr, csr_pos, *params)
+
     # ------------------------------------------------------------------ staged forward (tests / debugging)
     def simmim_forward_stages(self, img, bool_mask, idx):
         """Forward only, returning the intermediates the golden fixtures pin."""
@@ -210,3 +327,31 @@ class Engine:
         L = self.enc.depth
         return dict(loss=loss, tok_embed=tok_embed, tok_masked=x0, after_spatial=acts[L], enc_out=acts[-1],
                     pred=pred, dpred=dpred, acts=acts, x1s=x1s)
+
+
+class _SimMIMLossFn(torch.autograd.Function):
+    """loss = SimMIM(img); gradients of every parameter come from the HIP backward kernels and are
+    handed to autograd as views of the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, eng, names, img, mask_u8, idx32, csr_ptr, csr_pos, *params):
+        eng.prep_weights()
+        x0 = eng.tokenize(img, mask_u8)
+        acts, x1s = eng.blocks_fwd(x0, save=True)
+        loss, dpred, _ = eng.head_fwd(acts[-1], img, idx32)
+        ctx.eng = eng
+        ctx.names = names
+        ctx.stash = (img, mask_u8, csr_ptr, csr_pos, acts, x1s, dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        eng = ctx.eng
+        img, mask_u8, csr_ptr, csr_pos, acts, x1s, dpred = ctx.stash
+        ctx.stash = None
+        gout = gout.contiguous().float()
+        dy = eng.head_bwd(acts[-1], dpred, csr_ptr, csr_pos, gout)
+        dx0 = eng.blocks_bwd(acts, x1s, dy)
+        eng.tokenize_bwd(img, mask_u8, dx0)
+        grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
+        return (None,) * 7 + grads
