@@ -122,8 +122,8 @@ typedef struct MsstBlockGrads {
  * -> attention half, one workgroup per (tile chunk, head), weight grads in registers -> LN1
  * backward + residual; partial-gradient slabs are reduced in a fixed order (deterministic).
  * Workspace (caller-owned, device): dx1 [tokens][96] f32; dxn_part heads*tokens*96 elems
- * (f32 or bf16 by prec); slab max(grid_rows*MSST_MLP_SLAB, nchunk*heads*MSST_ATTN_SLAB,
- * grid_rows*MSST_LN1_SLAB) floats. */
+ * (f32 or bf16 by prec); slab grid_rows*(MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB
+ * floats. */
 int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/, const float* x,
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
                    int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,
@@ -143,6 +143,15 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
  * reference's value clamp of the gradient (pretrain.py:71-73) when clamp > 0. */
 int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, float clamp, float gscale, void* stream);
+
+/* Opt-in per-kernel timing: when enabled every kernel launch of the library is bracketed by a pair
+ * of HIP events recorded on the launch stream.  msst_profile_collect synchronises on the recorded
+ * events and returns, per kernel id (0 .. msst_profile_kernels()-1), the summed duration in ms and
+ * the launch count since enable / the previous collect.  Not thread-safe; meant for bench.py. */
+int msst_profile_enable(int on);
+int msst_profile_kernels(void);
+const char* msst_profile_name(int id);
+int msst_profile_collect(double* total_ms /*host*/, long* count /*host*/);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,10 @@ _SIGS = {
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "msst_profile_enable": (c_int, [c_int]),
+    "msst_profile_kernels": (c_int, []),
+    "msst_profile_name": (c_char_p, [c_int]),
+    "msst_profile_collect": (c_int, [_P, _P]),
     "msst_adamw": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                            c_float, c_float, _P]),
 }

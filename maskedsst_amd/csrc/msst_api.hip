@@ -3,6 +3,7 @@
 #include "msst_kernels.h"
 #include <stdio.h>
 #include <string.h>
+#include <vector>
 
 namespace msst {
 
@@ -32,6 +33,39 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
         const float v = j.src[src_i];
         if constexpr (sizeof(E) == 4) dst[i] = v; else dst[i] = f2bf(v);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// opt-in profiler: a pair of HIP events around each kernel launch, on the launch stream
+// ------------------------------------------------------------------------------------------
+struct ProfRec { int id; hipEvent_t a, b; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::vector<hipEvent_t> g_pool;
+static size_t g_pool_next = 0;
+static ProfRec* g_open = nullptr;
+
+static hipEvent_t pool_event() {
+    if (g_pool_next == g_pool.size()) {
+        hipEvent_t e;
+        hipEventCreate(&e);
+        g_pool.push_back(e);
+    }
+    return g_pool[g_pool_next++];
+}
+
+void prof_begin(int id, hipStream_t st) {
+    if (!g_prof_on) return;
+    ProfRec r;
+    r.id = id; r.a = pool_event(); r.b = pool_event();
+    hipEventRecord(r.a, st);
+    g_prof.push_back(r);
+    g_open = &g_prof.back();
+}
+void prof_end(hipStream_t st) {
+    if (!g_prof_on || !g_open) return;
+    hipEventRecord(g_open->b, st);
+    g_open = nullptr;
 }
 
 static TileMap make_tilemap(int mode, int B, int S, int N) {
@@ -65,8 +99,38 @@ extern "C" {
 int msst_version(void) { return MSST_VERSION; }
 const char* msst_last_error(void) { return g_err; }
 
+int msst_profile_enable(int on) {
+    g_prof_on = on != 0;
+    if (on) { g_prof.clear(); g_pool_next = 0; g_open = nullptr; }
+    return 0;
+}
+
+int msst_profile_kernels(void) { return K_COUNT; }
+
+const char* msst_profile_name(int id) {
+    static const char* names[K_COUNT] = {"prep_weights", "tokenize_fwd", "block_fwd", "head_fwd", "loss_reduce",
+                                         "head_bwd", "reduce_slabs", "block_bwd_mlp", "block_bwd_attn",
+                                         "attn_slab_reduce", "block_bwd_ln1", "tokenize_bwd", "pos_split", "adamw"};
+    return (id >= 0 && id < K_COUNT) ? names[id] : "?";
+}
+
+int msst_profile_collect(double* total_ms, long* count) {
+    for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0.0; count[i] = 0; }
+    for (const ProfRec& r : g_prof) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return fail(MSST_ERR_BADARG, "msst_profile_collect");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) continue;
+        total_ms[r.id] += ms;
+        count[r.id] += 1;
+    }
+    g_prof.clear();
+    g_pool_next = 0;
+    return 0;
+}
+
 int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int max_elems, int prec, void* stream) {
     if (njobs <= 0) return 0;
+    ProfScope ps(K_PREP, (hipStream_t)stream);
     int gx = (max_elems + 256 * 4 - 1) / (256 * 4);
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
@@ -122,13 +186,17 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
     int rc = launch_head_bwd(a, nchunk, st);
     if (rc) return fail(rc, "msst_head_bwd");
     const long ss = (long)P * 96 + P;
+    RSegBuilder rb;
     if (per_block) {
-        rc = launch_reduce_slabs(slab, S, nchunk * ss, nchunk, ss, dw_pix, (long)P * 96, P * 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + P * 96, S, nchunk * ss, nchunk, ss, db_pix, P, P, 0, st);
+        for (int c = 0; c < S; ++c) {
+            rb.add(slab + (long)c * nchunk * ss, ss, nchunk, dw_pix + (long)c * P * 96, P * 96);
+            rb.add(slab + (long)c * nchunk * ss + P * 96, ss, nchunk, db_pix + (long)c * P, P);
+        }
     } else {
-        rc = launch_reduce_slabs(slab, 1, 0, S * nchunk, ss, dw_pix, 0, P * 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + P * 96, 1, 0, S * nchunk, ss, db_pix, 0, P, 0, st);
+        rb.add(slab, ss, S * nchunk, dw_pix, P * 96);
+        rb.add(slab + P * 96, ss, S * nchunk, db_pix, P);
     }
+    rc = launch_reduce_segs(rb.r, st);
     return fail(rc, "msst_head_bwd(reduce)");
 }
 
@@ -140,48 +208,65 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     hipStream_t st = (hipStream_t)stream;
     const long ntok = (long)B * S * N;
     const BlockWeights bw = to_bw(w);
-    // 1. MLP half: dy -> dx1, slabs -> dW1 dW2 db1 db2 dln2
+    const int ntiles_rows = (int)((ntok + 63) / 64);
+    const int grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;
+    float* slab_mlp = slab;
+    float* slab_attn = slab_mlp + (long)grid * MSST_MLP_SLAB_N;
+    AttnBwdArgs aa;
+    aa.tm = make_tilemap(mode, B, S, N);
+    aa.ntiles = ntiles_of(aa.tm);
+    const int nc = nchunk < aa.ntiles ? nchunk : aa.ntiles;
+    float* slab_ln1 = slab_attn + (long)nc * heads * MSST_ATTN_SLAB_N;
+    // 1. MLP half: dy -> dx1
     {
         MlpBwdArgs a;
-        a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab; a.ntok = ntok;
-        const int ntiles = (int)((ntok + 63) / 64);
-        const int grid = grid_rows < ntiles ? grid_rows : ntiles;
+        a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok;
         int rc = launch_block_bwd_mlp(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
-        const long ss = MSST_MLP_SLAB_N;
-        rc = launch_reduce_slabs(slab, 1, 0, grid, ss, g->w1, 0, 6144, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 6144, 1, 0, grid, ss, g->w2, 0, 6144, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 12288, 1, 0, grid, ss, g->b1, 0, 64, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 64, 1, 0, grid, ss, g->b2, 0, 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 160, 1, 0, grid, ss, g->ln2_g, 0, 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 12288 + 256, 1, 0, grid, ss, g->ln2_b, 0, 96, 0, st);
-        if (rc) return fail(rc, "msst_block_bwd(mlp reduce)");
     }
     // 2. attention half, per (chunk, head)
     {
-        AttnBwdArgs a;
-        a.w = bw; a.x = x; a.da = dx1; a.dxn_part = dxn_part; a.slab = slab;
-        a.tm = make_tilemap(mode, B, S, N);
-        a.ntiles = ntiles_of(a.tm);
-        a.H = heads; a.ntok = ntok; a.scale = 0.125f;
-        const int nc = nchunk < a.ntiles ? nchunk : a.ntiles;
-        int rc = launch_block_bwd_attn(a, nc, prec, st);
+        aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
+        aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f;
+        int rc = launch_block_bwd_attn(aa, nc, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(attn)");
-        rc = launch_attn_slab_reduce(slab, nc, heads, g->wqkv, g->wout, st);
-        if (rc) return fail(rc, "msst_block_bwd(attn reduce)");
     }
     // 3. LN1 backward + residual
     {
         Ln1BwdArgs a;
-        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab; a.ntok = ntok; a.H = heads;
-        const int ntiles = (int)((ntok + 63) / 64);
-        const int grid = grid_rows < ntiles ? grid_rows : ntiles;
+        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = heads;
         int rc = launch_block_bwd_ln1(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(ln1)");
-        rc = launch_reduce_slabs(slab, 1, 0, grid, 288, g->ln1_g, 0, 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 96, 1, 0, grid, 288, g->ln1_b, 0, 96, 0, st);
-        if (!rc) rc = launch_reduce_slabs(slab + 192, 1, 0, grid, 288, g->bo, 0, 96, 0, st);
-        if (rc) return fail(rc, "msst_block_bwd(ln1 reduce)");
+    }
+    // 4. one deterministic reduction of all partial-gradient slabs of the block
+    {
+        RSegBuilder rb;
+        const long ms = MSST_MLP_SLAB_N;
+        bool ok = rb.add(slab_mlp, ms, grid, g->w1, 6144);
+        ok = ok && rb.add(slab_mlp + 6144, ms, grid, g->w2, 6144);
+        ok = ok && rb.add(slab_mlp + 12288, ms, grid, g->b1, 64);
+        ok = ok && rb.add(slab_mlp + 12288 + 64, ms, grid, g->b2, 96);
+        ok = ok && rb.add(slab_mlp + 12288 + 160, ms, grid, g->ln2_g, 96);
+        ok = ok && rb.add(slab_mlp + 12288 + 256, ms, grid, g->ln2_b, 96);
+        ok = ok && rb.add(slab_ln1, 288, grid, g->ln1_g, 96);
+        ok = ok && rb.add(slab_ln1 + 96, 288, grid, g->ln1_b, 96);
+        ok = ok && rb.add(slab_ln1 + 192, 288, grid, g->bo, 96);
+        const long as = (long)heads * MSST_ATTN_SLAB_N;
+        const int inner = heads * 64;
+        for (int h = 0; h < heads && ok; ++h) {
+            const float* sh = slab_attn + (long)h * MSST_ATTN_SLAB_N;
+            for (int which = 0; which < 3 && ok; ++which)
+                ok = rb.add(sh + which * 6144, as, nc, g->wqkv + ((long)(which * heads + h) * 64) * 96, 6144);
+            ok = ok && rb.add(sh + 3 * 6144, as, nc, g->wout + h * 64, 6144, 64, inner);
+            if (rb.r.nseg > MSST_MAX_RSEG - 4 && h + 1 < heads) {   // flush when the table is nearly full
+                int rc = launch_reduce_segs(rb.r, st);
+                if (rc) return fail(rc, "msst_block_bwd(reduce)");
+                rb = RSegBuilder();
+            }
+        }
+        if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd(reduce table)");
+        int rc = launch_reduce_segs(rb.r, st);
+        if (rc) return fail(rc, "msst_block_bwd(reduce)");
     }
     return 0;
 }
@@ -202,18 +287,29 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
     const long ss = (long)N * 96 + 96 * P + 96 * 4 + 32;
     const long bs = (long)nchunk * ss;
     float* stage = slab + (long)S * nchunk * ss;  // [S][N][96] position-gradient staging
-    // per spectral block: position rows, embed weight, embed bias
     float* dpos_dst = pos_split ? stage : dpos_a;
-    rc = launch_reduce_slabs(slab, S, bs, nchunk, ss, dpos_dst, (long)N * 96, N * 96, 0, st);
-    if (!rc) rc = launch_reduce_slabs(slab + N * 96, S, bs, nchunk, ss, dw_emb, 96 * P, 96 * P, 0, st);
     const long v0 = (long)N * 96 + 96 * P;
-    if (!rc) rc = launch_reduce_slabs(slab + v0, S, bs, nchunk, ss, db_emb, 96, 96, 0, st);
+    RSegBuilder rb;
+    bool ok = true;
+    for (int c = 0; c < S && ok; ++c) {   // per spectral block: position rows, embed weight, embed bias
+        const float* sc = slab + c * bs;
+        ok = rb.add(sc, ss, nchunk, dpos_dst + (long)c * N * 96, N * 96);
+        ok = ok && rb.add(sc + N * 96, ss, nchunk, dw_emb + (long)c * 96 * P, 96 * P);
+        ok = ok && rb.add(sc + v0, ss, nchunk, db_emb + (long)c * 96, 96);
+        if (rb.r.nseg > MSST_MAX_RSEG - 8) {
+            rc = launch_reduce_segs(rb.r, st);
+            if (rc) return fail(rc, "msst_tokenize_bwd(reduce)");
+            rb = RSegBuilder();
+        }
+    }
     // shared across blocks
-    if (!rc) rc = launch_reduce_slabs(slab + v0 + 96, 1, 0, S * nchunk, ss, dpost_g, 0, 96, 0, st);
-    if (!rc) rc = launch_reduce_slabs(slab + v0 + 192, 1, 0, S * nchunk, ss, dpost_b, 0, 96, 0, st);
-    if (!rc && dmask_token) rc = launch_reduce_slabs(slab + v0 + 288, 1, 0, S * nchunk, ss, dmask_token, 0, 96, 0, st);
-    if (!rc) rc = launch_reduce_slabs(slab + v0 + 384, 1, 0, S * nchunk, ss, dpre_g, 0, P, 0, st);
-    if (!rc) rc = launch_reduce_slabs(slab + v0 + 384 + 16, 1, 0, S * nchunk, ss, dpre_b, 0, P, 0, st);
+    ok = ok && rb.add(slab + v0 + 96, ss, S * nchunk, dpost_g, 96);
+    ok = ok && rb.add(slab + v0 + 192, ss, S * nchunk, dpost_b, 96);
+    if (dmask_token) ok = ok && rb.add(slab + v0 + 288, ss, S * nchunk, dmask_token, 96);
+    ok = ok && rb.add(slab + v0 + 384, ss, S * nchunk, dpre_g, P);
+    ok = ok && rb.add(slab + v0 + 384 + 16, ss, S * nchunk, dpre_b, P);
+    if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_tokenize_bwd(reduce table)");
+    rc = launch_reduce_segs(rb.r, st);
     if (!rc && pos_split) rc = launch_pos_split(stage, S, N, pos_split, dpos_a, dpos_b, st);
     return fail(rc, "msst_tokenize_bwd(reduce)");
 }

@@ -64,18 +64,27 @@ __global__ __launch_bounds__(384) void head_bwd_kernel(HeadBwdArgs a) {
 }
 
 // ==========================================================================================
-// reduce_slabs: out[bt][i] (+)= sum_s slab[bt*batch_stride + s*slab_stride + i]
+// reduce_segs: deterministic reduction of per-workgroup partial-gradient slabs, all segments of one
+// backward stage in ONE launch.  A 256-thread block owns 32 consecutive outputs of one segment:
+// 8 thread groups stride over the slabs, partials are combined through LDS in a fixed order.
 // ==========================================================================================
-__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slab, long batch_stride, int nslab,
-                                                           long slab_stride, float* out, long out_batch_stride,
-                                                           int n, int accumulate) {
-    const int bt = blockIdx.y;
-    const float* src = slab + (long)bt * batch_stride;
-    float* dst = out + (long)bt * out_batch_stride;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < nslab; ++k) s += src[(long)k * slab_stride + i];
-        dst[i] = accumulate ? dst[i] + s : s;
+__global__ __launch_bounds__(256) void reduce_segs_kernel(RSegs r) {
+    __shared__ float part[8][33];
+    int si = 0;
+    while (si + 1 < r.nseg && (int)blockIdx.x >= r.s[si + 1].blk0) ++si;
+    const RSeg g = r.s[si];
+    const int io = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    const int i = ((int)blockIdx.x - g.blk0) * 32 + io;
+    float s = 0.f;
+    if (i < g.n)
+        for (int k = sg; k < g.nslab; k += 8) s += g.src[(long)k * g.slab_stride + i];
+    part[sg][io] = s;
+    __syncthreads();
+    if (sg == 0 && i < g.n) {
+        const float t = ((part[0][io] + part[1][io]) + (part[2][io] + part[3][io])) +
+                        ((part[4][io] + part[5][io]) + (part[6][io] + part[7][io]));
+        const int row = i / g.row_len, col = i - row * g.row_len;
+        g.dst[(long)row * g.row_stride + col] = t;
     }
 }
 
@@ -600,25 +609,6 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
 template __global__ void block_bwd_attn_kernel<PF32>(AttnBwdArgs);
 template __global__ void block_bwd_attn_kernel<PBF16>(AttnBwdArgs);
 
-// scatter-reduce of the attention slabs into to_qkv.weight.grad [3*H*64][96] and to_out.0.weight.grad
-// [96][H*64]:  slab[chunk][h][...] summed over chunks.
-__global__ __launch_bounds__(256) void attn_slab_reduce_kernel(const float* slab, int nchunk, int H, float* dwqkv,
-                                                               float* dwout) {
-    const int h = blockIdx.y;
-    const int inner = H * 64;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < MSST_ATTN_SLAB_N; i += gridDim.x * 256) {
-        float s = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) s += slab[((long)ch * H + h) * MSST_ATTN_SLAB_N + i];
-        if (i < 3 * 6144) {
-            const int which = i / 6144, rem = i - which * 6144;  // rem = d*96 + m
-            dwqkv[((long)(which * H + h) * 64) * 96 + rem] = s;
-        } else {
-            const int rem = i - 3 * 6144, m = rem / 64, d = rem - m * 64;
-            dwout[(long)m * inner + h * 64 + d] = s;
-        }
-    }
-}
-
 // ==========================================================================================
 // LN1 backward + residual:  dx = dx1 + LN1_bwd(sum_h part[h]; x)   (vit_spatial_spectral.py:22-29,:102)
 // persistent grid over 64-token tiles; 4 threads per row, 24 features each.
@@ -884,17 +874,15 @@ __global__ __launch_bounds__(256) void pos_split_kernel(const float* dpos /*[S][
 // ------------------------------------------------------------------------------------------
 int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    ProfScope ps(K_HEAD_BWD, st);
     hipLaunchKernelGGL(head_bwd_kernel, dim3(a.S, nchunk), dim3(384), 0, st, a);
     return (int)hipGetLastError();
 }
 
-int launch_reduce_slabs(const float* slab, int nbatch, long batch_stride, int nslab, long slab_stride, float* out,
-                        long out_batch_stride, int n, int accumulate, hipStream_t st) {
-    if (n <= 0 || nbatch <= 0) return 0;
-    int gx = (n + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(gx, nbatch), dim3(256), 0, st, slab, batch_stride, nslab, slab_stride,
-                       out, out_batch_stride, n, accumulate);
+int launch_reduce_segs(const RSegs& r, hipStream_t st) {
+    if (r.nseg <= 0 || r.nblocks <= 0) return 0;
+    ProfScope ps(K_REDUCE, st);
+    hipLaunchKernelGGL(reduce_segs_kernel, dim3(r.nblocks), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 
@@ -915,11 +903,13 @@ int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st
         const size_t smem = sizeof(MlpBwdSmem<PF32>);
         int rc = set_smem(&block_bwd_mlp_kernel<PF32>, smem, d0);
         if (rc) return rc;
+        ProfScope ps(K_BWD_MLP, st);
         hipLaunchKernelGGL(block_bwd_mlp_kernel<PF32>, dim3(grid), dim3(256), smem, st, a);
     } else {
         const size_t smem = sizeof(MlpBwdSmem<PBF16>);
         int rc = set_smem(&block_bwd_mlp_kernel<PBF16>, smem, d1);
         if (rc) return rc;
+        ProfScope ps(K_BWD_MLP, st);
         hipLaunchKernelGGL(block_bwd_mlp_kernel<PBF16>, dim3(grid), dim3(256), smem, st, a);
     }
     return (int)hipGetLastError();
@@ -933,22 +923,20 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
         const size_t smem = sizeof(AttnBwdSmem<PF32>);
         int rc = set_smem(&block_bwd_attn_kernel<PF32>, smem, d0);
         if (rc) return rc;
+        ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
     } else {
         const size_t smem = sizeof(AttnBwdSmem<PBF16>);
         int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);
         if (rc) return rc;
+        ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PBF16>, grid, dim3(256), smem, st, a);
     }
     return (int)hipGetLastError();
 }
 
-int launch_attn_slab_reduce(const float* slab, int nchunk, int H, float* dwqkv, float* dwout, hipStream_t st) {
-    hipLaunchKernelGGL(attn_slab_reduce_kernel, dim3(24, H), dim3(256), 0, st, slab, nchunk, H, dwqkv, dwout);
-    return (int)hipGetLastError();
-}
-
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st) {
+    ProfScope ps(K_BWD_LN1, st);
     if (prec == MSST_PREC_F32) hipLaunchKernelGGL(block_bwd_ln1_kernel<float>, dim3(grid), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(block_bwd_ln1_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, a);
     return (int)hipGetLastError();
@@ -956,12 +944,14 @@ int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st
 
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    ProfScope ps(K_TOK_BWD, st);
     hipLaunchKernelGGL(tokenize_bwd_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
 int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st) {
     const int n = N * split + S * (96 - split);
+    ProfScope ps(K_POS_SPLIT, st);
     hipLaunchKernelGGL(pos_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dpos, S, N, split, dpe, dce);
     return (int)hipGetLastError();
 }

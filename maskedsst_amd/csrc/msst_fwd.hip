@@ -389,6 +389,7 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* partial, 
 // ------------------------------------------------------------------------------------------
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
+    ProfScope ps(K_TOK_FWD, st);
     hipLaunchKernelGGL(tokenize_fwd_kernel, dim3(a.S, a.B), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
@@ -403,6 +404,7 @@ static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
+    ProfScope ps(K_BLOCK_FWD, st);
     hipLaunchKernelGGL(block_fwd_kernel<P>, dim3(grid), dim3(256), smem, st, a);
     return (int)hipGetLastError();
 }
@@ -417,9 +419,11 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {
     if (a.P > 16) return MSST_ERR_UNSUPPORTED;
     dim3 grid((a.K + 63) / 64, a.B);
-    hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(256), 0, st, a);
+    { ProfScope ps(K_HEAD_FWD, st);
+    hipLaunchKernelGGL(head_fwd_kernel, grid, dim3(256), 0, st, a); }
     const int np = grid.x * grid.y;
     const float scale = 1.0f / ((float)a.B * (float)a.K * (float)a.P) / (float)a.K;
+    ProfScope ps(K_LOSS_REDUCE, st);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, a.partial, np, scale, loss);
     return (int)hipGetLastError();
 }

@@ -99,13 +99,45 @@ struct TokBwdArgs {
     int B, S, N, T, P;
 };
 
+// ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
+enum KernelId {
+    K_PREP = 0, K_TOK_FWD, K_BLOCK_FWD, K_HEAD_FWD, K_LOSS_REDUCE, K_HEAD_BWD, K_REDUCE, K_BWD_MLP, K_BWD_ATTN,
+    K_ATTN_REDUCE, K_BWD_LN1, K_TOK_BWD, K_POS_SPLIT, K_ADAMW, K_COUNT
+};
+void prof_begin(int id, hipStream_t st);
+void prof_end(hipStream_t st);
+struct ProfScope {
+    hipStream_t st;
+    ProfScope(int id, hipStream_t s) : st(s) { prof_begin(id, s); }
+    ~ProfScope() { prof_end(st); }
+};
+
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st);
-int launch_reduce_slabs(const float* slab, int nbatch, long batch_stride, int nslab, long slab_stride, float* out,
-                        long out_batch_stride, int n, int accumulate, hipStream_t st);
+// One reduction segment: dst[(i / row_len) * row_stride + i % row_len] = sum_{k < nslab} src[k * slab_stride + i], i < n
+struct RSeg {
+    const float* src; float* dst;
+    long slab_stride;
+    int nslab, n, row_len, row_stride, blk0, _pad;
+};
+#define MSST_MAX_RSEG 72
+struct RSegs { RSeg s[MSST_MAX_RSEG]; int nseg; int nblocks; };
+struct RSegBuilder {
+    RSegs r;
+    RSegBuilder() { r.nseg = 0; r.nblocks = 0; }
+    bool add(const float* src, long slab_stride, int nslab, float* dst, int n, int row_len = 0, int row_stride = 0) {
+        if (r.nseg >= MSST_MAX_RSEG) return false;
+        RSeg& g = r.s[r.nseg++];
+        g.src = src; g.dst = dst; g.slab_stride = slab_stride; g.nslab = nslab; g.n = n;
+        g.row_len = row_len > 0 ? row_len : n; g.row_stride = row_stride > 0 ? row_stride : n;
+        g.blk0 = r.nblocks; g._pad = 0;
+        r.nblocks += (n + 31) / 32;
+        return true;
+    }
+};
+int launch_reduce_segs(const RSegs& r, hipStream_t st);
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st);
-int launch_attn_slab_reduce(const float* slab, int nchunk, int H, float* dwqkv, float* dwout, hipStream_t st);
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st);
 int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st);

@@ -54,6 +54,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
     long blocks = (n / 4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    ProfScope ps(K_ADAMW, st);
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m, v, n, lr, b1, b2, eps, wd, bc1,
                        bc2_sqrt, clamp, gscale);
     return (int)hipGetLastError();

@@ -45,8 +45,8 @@ class Engine:
         self.fp = FlatParams(encoder, mim)
         self.prec = _prec_of(getattr(encoder, "precision", None))
         self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
-        self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "512"))      # persistent grid of the row-wise bwd kernels
-        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "64"))  # x heads workgroups in the attention bwd
+        self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "256"))      # persistent grid of the row-wise bwd kernels
+        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "32"))  # x heads workgroups in the attention bwd
         self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "16"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self._wbuf = None
@@ -240,7 +240,7 @@ class Engine:
         esz = 4 if self.prec == PREC_F32 else 2
         dx1 = torch.empty(ntok * 96, dtype=torch.float32, device=dev)
         part = torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev)
-        nslab = max(self.grid_rows * MLP_SLAB, self.attn_chunks * H * ATTN_SLAB, self.grid_rows * LN1_SLAB)
+        nslab = self.grid_rows * (MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
         slab = torch.empty(nslab, dtype=torch.float32, device=dev)
         layers = self._layers()
         g = dy
@@ -349,6 +349,13 @@ class _SimMIMLossFn(torch.autograd.Function):
         eng = ctx.eng
         img, mask_u8, csr_ptr, csr_pos, acts, x1s, dpred = ctx.stash
         ctx.stash = None
+        lo, hi = eng.fp.grad.data_ptr(), eng.fp.grad.data_ptr() + 4 * eng.fp.grad.numel()
+        for _, p in eng.trainable():
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                raise RuntimeError(
+                    "maskedsst_amd hands autograd views of its flat gradient buffer: drop the previous gradients "
+                    "with optimizer.zero_grad(set_to_none=True) (the torch default) before the next backward; "
+                    "in-place gradient accumulation across backward calls is not supported")
         gout = gout.contiguous().float()
         dy = eng.head_bwd(acts[-1], dpred, csr_ptr, csr_pos, gout)
         dx0 = eng.blocks_bwd(acts, x1s, dy)

@@ -1,0 +1,145 @@
+"""Fused AdamW + data-parallel gradient reduction for maskedsst_amd models.
+
+``FusedAdamW`` is a ``torch.optim.Optimizer`` (so LR schedulers such as the reference's
+``ReduceLROnPlateau``, ``src/utils.py:47-50``, drive it unchanged) whose ``step`` is ONE launch of
+``msst_adamw`` over the flat parameter buffer instead of ~350 small tensor updates.  It reproduces
+``torch.optim.AdamW`` (reference ``src/utils.py:41-44``) including the "parameters without a
+gradient are skipped" rule: ``encoder.mlp_head.*`` receives no gradient in pre-training and lies
+outside the updated range.  ``grad_clamp`` applies the reference's per-parameter gradient hook
+``clamp(grad, -1, 1)`` (``pretrain.py:71-73``) inside the kernel, after the data-parallel mean.
+
+``BucketReducer`` all-reduces slices of the flat gradient buffer as soon as the backward has
+completed them (buckets are contiguous because the flat layout follows backward order), on the
+process group's own stream (``torch.distributed`` NCCL backend == RCCL on ROCm), overlapping the
+remaining backward kernels.  It only needs a flat tensor and a bucket list, so the gloo tests
+exercise the same code on CPU tensors.
+"""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+
+class BucketReducer:
+    def __init__(self, flat_grad, buckets, group=None, bucket_bytes=4 << 20, average_in_optimizer=True):
+        """buckets: [(name, start, end)] in the order the backward completes them."""
+        self.flat = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_bytes = bucket_bytes
+        self.average_in_optimizer = average_in_optimizer
+        self.order = [b[0] for b in buckets]
+        self.range = {b[0]: (b[1], b[2]) for b in buckets}
+        self.reset()
+
+    def reset(self):
+        self.handles = []
+        self.pending = None  # (start, end) of completed-but-unsent contiguous range
+        self.done = set()
+
+    def bucket_ready(self, name, start=None, end=None):
+        """called (in backward order) when a bucket's gradients are final"""
+        if self.world == 1:
+            return
+        s, e = self.range[name]
+        self.done.add(name)
+        if self.pending is None:
+            self.pending = (s, e)
+        elif self.pending[1] == s:
+            self.pending = (self.pending[0], e)
+        else:  # non-contiguous: flush what we have, start a new run
+            self._flush()
+            self.pending = (s, e)
+        if (self.pending[1] - self.pending[0]) * self.flat.element_size() >= self.bucket_bytes:
+            self._flush()
+
+    def _flush(self):
+        if self.pending is None:
+            return
+        s, e = self.pending
+        self.pending = None
+        if e > s:
+            h = dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.handles.append(h)
+
+    def finish(self):
+        """flush the tail and wait for every outstanding all-reduce; returns the scale still to be
+        applied to the gradients (1/world when the optimizer does the averaging)."""
+        if self.world > 1:
+            self._flush()
+            for h in self.handles:
+                h.wait()
+            if not self.average_in_optimizer:
+                lo = min(self.range[n][0] for n in self.order)
+                hi = max(self.range[n][1] for n in self.order)
+                self.flat[lo:hi].mul_(1.0 / self.world)
+        self.handles = []
+        self.done = set()
+        return (1.0 / self.world) if self.average_in_optimizer else 1.0
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_clamp=0.0):
+        params = [p for p in model.parameters()]
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self.grad_clamp = float(grad_clamp)
+        self.grad_scale = 1.0
+        self._m = None
+        self._v = None
+        self._step = 0
+        self._flat_id = None
+
+    def _state(self, eng):
+        eng.ensure()
+        flat = eng.fp.flat
+        if self._m is None or self._flat_id != flat.data_ptr():
+            # (re)allocate moments; a re-flatten (e.g. after .to()) carries the old moments over
+            m = torch.zeros_like(flat)
+            v = torch.zeros_like(flat)
+            if self._m is not None and self._m.numel() == m.numel():
+                m.copy_(self._m)
+                v.copy_(self._v)
+            self._m, self._v = m, v
+            self._flat_id = flat.data_ptr()
+        return flat, eng.fp.grad, self._m, self._v
+
+    def zero_grad(self, set_to_none=True):
+        # The backward overwrites the flat gradient buffer and hands autograd VIEWS of it, so the
+        # .grad attributes must be dropped (not zeroed, not kept): a surviving .grad would make
+        # autograd accumulate a view onto itself.
+        return super().zero_grad(set_to_none=True)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        from . import _lib
+        eng = self.model.engine()
+        flat, grad, m, v = self._state(eng)
+        g = self.param_groups[0]
+        self._step += 1
+        n = eng.fp.n_trainable
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        P = lambda t: ctypes.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(eng.lib.msst_adamw(P(flat), P(grad), P(m), P(v), n, float(g["lr"]), float(g["betas"][0]),
+                                      float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step,
+                                      self.grad_clamp, float(self.grad_scale), stream), "msst_adamw")
+        return None
+
+    def state_dict(self):
+        d = super().state_dict()
+        d["fused"] = dict(step=self._step, m=self._m, v=self._v)
+        return d
+
+
+def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
+    """Make ``model`` (a SimMIMSpatialSpectral) data parallel over ``group``: masks are drawn for
+    the global batch, gradient buckets are all-reduced as the backward completes them.  Returns the
+    reducer; call ``reducer.finish()`` after ``loss.backward()`` and hand its return value to
+    ``optimizer.grad_scale``."""
+    eng = model.engine()
+    eng.ensure()
+    model.dp_rank = dist.get_rank(group) if dist.is_initialized() else 0
+    model.dp_world = dist.get_world_size(group) if dist.is_initialized() else 1
+    red = BucketReducer(eng.fp.grad, eng.fp.buckets, group=group, bucket_bytes=bucket_bytes)
+    eng.bucket_hook = red.bucket_ready
+    return red
