@@ -311,6 +311,33 @@ class Engine:
             return loss
         return _SimMIMLossFn.apply(self, names, img, mask_u8, idx32, csr_ptr, csr_pos, *params)
 
+    # ------------------------------------------------------------------ encoder-level API (inference)
+    def transformer(self, tokens):
+        """ViTSpatialSpectral.transformer_forward: both stacks on [B, T, 96] tokens (forward only)."""
+        self._require_cuda(tokens)
+        if torch.is_grad_enabled() and tokens.requires_grad:
+            raise NotImplementedError("autograd through transformer_forward alone is not wired up yet; "
+                                      "train through SimMIMSpatialSpectral")
+        self.prep_weights()
+        acts, _ = self.blocks_fwd(tokens.contiguous().float(), save=False)
+        return acts[-1]
+
+    def embed_patches(self, patches):
+        """BlockwisePatchEmbedding.embed on patches [B, S, N, P] (no position / mask terms)."""
+        self._require_cuda(patches)
+        B, S, N, P = patches.shape
+        img = patches.permute(0, 1, 3, 2).reshape(B, S * P, N).contiguous()
+        return self.tokenize(img, None, with_pos=False)
+
+    def features(self, img):
+        """forward_features (eval): tokenize + pos -> transformer"""
+        x0 = self.tokenize(img, None, with_pos=True)
+        return self.transformer(x0)
+
+    def classify(self, img):
+        raise NotImplementedError("the classification head path (finetune.py) is a 'next' row of the scope table "
+                                  "and is not built yet")
+
     # ------------------------------------------------------------------ staged forward (tests / debugging)
     def simmim_forward_stages(self, img, bool_mask, idx):
         """Forward only, returning the intermediates the golden fixtures pin."""

@@ -172,7 +172,7 @@ class ViTSpatialSpectral(nn.Module):
         self.patch_depth = spectral_patch_size
         self.image_size = image_size
         self.pixels_per_patch = reduce(mul, [self.patch_depth, self.patch_height, self.patch_width])
-        self.spectral_pos = np.array(spectral_pos)
+        self.spectral_pos = np.asarray(spectral_pos.tolist() if torch.is_tensor(spectral_pos) else spectral_pos)
         self.spectral_pos_embed = spectral_pos_embed
         self.blockwise_patch_embed = blockwise_patch_embed
         self.spectral_only = spectral_only

