@@ -320,11 +320,10 @@ struct AttnBwdSmem {
 };
 
 template <class P>
-__device__ __forceinline__ void ln1_rows_to_lds(const float* x, const float* gam, const float* bet, const TileMap& tm,
-                                                int tile, typename P::elem (*dst)[96 + P::PADE]) {
+__device__ __forceinline__ void ln1_rows_to_lds(const float* x, const float* gam, const float* bet, long tok,
+                                                typename P::elem (*dst)[96 + P::PADE]) {
     const int tid = threadIdx.x;
     const int r = tid >> 2, part = tid & 3;
-    const long tok = tm.token(tile, r);
     float v[24];
     if (tok >= 0) {
         const f32x4* src = reinterpret_cast<const f32x4*>(x + tok * 96 + part * 24);
@@ -352,7 +351,7 @@ __device__ __forceinline__ void ln1_rows_to_lds(const float* x, const float* gam
 }
 
 template <class P>
-__global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
+__global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(AttnBwdArgs a) {
     typedef typename P::elem elem;
     typedef typename P::frag frag;
     typedef AttnBwdSmem<P> SM;
@@ -375,8 +374,16 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) { gq[i] = zero4(); gk[i] = zero4(); gv[i] = zero4(); go[i] = zero4(); }
 
+    const int2 sp_ln = tm.row_sp(tid >> 2);
+    const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;
+    constexpr int CPR = 96 * (int)sizeof(elem) / 16;   // 16-byte chunks per row (copy-out of the partial)
+    int2 sp_out[(16 * CPR) / 64];
+#pragma unroll
+    for (int it = 0; it < (16 * CPR) / 64; ++it) sp_out[it] = tm.row_sp(wave * 16 + (it * 64 + l) / CPR);
+
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tm, tile, sm.xd);
+        const long tok_ln = tm.token_sp(tile, sp_ln);
+        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tok_ln, sm.xd);
         __syncthreads();
         // ---------------- phase A: q, k, v^T (wave <-> 16 head channels) ----------------
         {
@@ -410,7 +417,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
         // ---------------- da rows -> xd (overwrites LN1(x); rows of this wave only) ----------------
         {
             const int r = tid >> 2, pt = tid & 3;
-            const long tok = tm.token(tile, r);
+            const long tok = tok_ln;
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 f32x4 t4 = zero4();
@@ -430,14 +437,13 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) pr[t] = P::mma(P::ld_kc(&sm.k[t * 16][k0], LDH), qb, pr[t]);  // C[i = key][j = query]
             }
-            const int qseq = (wave * 16 + c) / L;
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * 16 + 4 * g + r;
-                    const float v = (key / L == qseq) ? pr[t][r] * a.scale : -INFINITY;
+                    const float v = (key >= qlo && key < qhi) ? pr[t][r] * a.scale : -INFINITY;
                     pr[t][r] = v;
                     mx = fmaxf(mx, v);
                 }
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = expf(pr[t][r] - mx); pr[t][r] = e; sum += e; }
+                for (int r = 0; r < 4; ++r) { const float e = P::exp(pr[t][r] - mx); pr[t][r] = e; sum += e; }
             sum = colgroup_sum(sum);
             const float inv = 1.f / sum;
 #pragma unroll
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
             P::st_nat(&sm.k[wave * 16][t * 16], LDH, dk[t]);
             P::st_nat(&sm.vt[wave * 16][t * 16], LDH, dv[t]);
         }
-        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tm, tile, sm.xd);
+        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tok_ln, sm.xd);
         __syncthreads();
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
 #pragma unroll P::UNROLL
@@ -573,23 +579,23 @@ __global__ __launch_bounds__(256, 1) void block_bwd_attn_kernel(AttnBwdArgs a) {
                     dx[t] = P::mma(P::ld_kc(wt + 2 * inner, 3 * inner), bv, dx[t]);
                 }
             }
-            const long tok = tm.token(tile, wave * 16 + c);
-            if (tok >= 0) {
+            // stage the [16 x 96] result rows of this wave in xd (dead now) and write whole rows
+            __syncthreads();   // every wave is done reading xd (weight-grad loop above)
 #pragma unroll
-                for (int t = 0; t < 6; ++t) {
-                    elem* dst = part + tok * 96 + t * 16 + 4 * g;
-                    if constexpr (sizeof(elem) == 4) {
-                        *reinterpret_cast<f32x4*>(dst) = dx[t];
-                    } else {
-                        s16x4 v4;
-                        v4[0] = (short)f2bf(dx[t][0]); v4[1] = (short)f2bf(dx[t][1]);
-                        v4[2] = (short)f2bf(dx[t][2]); v4[3] = (short)f2bf(dx[t][3]);
-                        *reinterpret_cast<s16x4*>(dst) = v4;
-                    }
+            for (int t = 0; t < 6; ++t) P::st_nat(&sm.xd[wave * 16][t * 16], LDX, dx[t]);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (16 * CPR) / 64; ++it) {
+                const int idx = it * 64 + l, rr = idx / CPR, ch = idx - rr * CPR;
+                const long tok = tm.token_sp(tile, sp_out[it]);
+                if (tok >= 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(&sm.xd[wave * 16 + rr][0]) + ch * 16);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(part + tok * 96) + ch * 16) = v;
                 }
             }
         }
-        __syncthreads();
+        // no block barrier here: the next tile's LN1 only writes this wave's own xd rows, and q/k/vt
+        // are not touched before the barrier that follows it
     }
 
     // ---------------- slab: [dWq | dWk | dWv] [3][64][96], dWout_h [96][64] ----------------

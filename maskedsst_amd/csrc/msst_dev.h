@@ -23,13 +23,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef uint16_t bf16_t;
+typedef __bf16 hbf16x4 __attribute__((ext_vector_type(4)));
 
+// fp32 -> bf16, round-to-nearest-even in hardware (v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    // round-to-nearest-even; NaN stays NaN
-    uint32_t r = u + 0x7FFFu + ((u >> 16) & 1u);
-    if ((u & 0x7F800000u) == 0x7F800000u && (u & 0x007FFFFFu)) r = u | 0x00400000u;
-    return (bf16_t)(r >> 16);
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, b);
+}
+__device__ __forceinline__ s16x4 f2bf4(f32x4 c) {
+    return __builtin_bit_cast(s16x4, __builtin_convertvector(c, hbf16x4));
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
 
@@ -44,9 +46,11 @@ struct PF32 {
     static constexpr int KS = 4;    // k per MFMA
     static constexpr int UNROLL = 2;          // k-loop unroll (24 / 16 steps per GEMM)
     static constexpr int WAVES_PER_SIMD = 1;  // launch-bounds occupancy target (LDS allows 1 WG/CU)
+    static constexpr int WAVES_BWD_ATTN = 1;
     static constexpr int PADE = 4;  // LDS row padding in elements (16 bytes)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
     static __device__ __forceinline__ float up(elem e) { return e; }
+    static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -77,11 +81,13 @@ struct PBF16 {
     typedef bf16_t elem;
     typedef s16x8 frag;
     static constexpr int KS = 32;
-    static constexpr int UNROLL = 3;
+    static constexpr int UNROLL = 1;   // k-loops have 2-3 steps; full unrolling only inflates registers
     static constexpr int WAVES_PER_SIMD = 2;
+    static constexpr int WAVES_BWD_ATTN = 2;  // 2 workgroups per CU (LDS 76 KB each)
     static constexpr int PADE = 8;  // 16 bytes
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
     static __device__ __forceinline__ float up(elem e) { return bf2f(e); }
+    static __device__ __forceinline__ float exp(float x) { return __expf(x); }   // v_exp_f32; probabilities are rounded to bf16 anyway
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
@@ -108,9 +114,7 @@ struct PBF16 {
     }
     static __device__ __forceinline__ void st_nat(elem* p, int ld, f32x4 c) {
         const int l = lane_id();
-        s16x4 v;
-        v[0] = (short)f2bf(c[0]); v[1] = (short)f2bf(c[1]); v[2] = (short)f2bf(c[2]); v[3] = (short)f2bf(c[3]);
-        *reinterpret_cast<s16x4*>(p + (l & 15) * ld + 4 * (l >> 4)) = v;
+        *reinterpret_cast<s16x4*>(p + (l & 15) * ld + 4 * (l >> 4)) = f2bf4(c);
     }
     static __device__ __forceinline__ void st_tr(elem* p, int ld, f32x4 c) {
         const int l = lane_id();
@@ -159,6 +163,19 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; retur
 // ------------------------------------------------------------------------------------------
 struct TileMap {
     int mode, L, TS, N, T, nseq;
+    // loop-invariant part of a row: (sequence slot s, position p); s < 0 marks a padding row
+    __device__ __forceinline__ int2 row_sp(int r) const {
+        const int s = r / L;
+        return s >= TS ? make_int2(-1, 0) : make_int2(s, r - s * L);
+    }
+    __device__ __forceinline__ long token_sp(int tile, int2 sp) const {
+        if (sp.x < 0) return -1;
+        const int q = tile * TS + sp.x;
+        if (q >= nseq) return -1;
+        if (mode == 0) return (long)q * N + sp.y;
+        const int b = q / N, n = q - b * N;
+        return (long)b * T + (long)sp.y * N + n;
+    }
     __device__ __forceinline__ long token(int tile, int r) const {
         const int s = r / L;
         if (s >= TS) return -1;

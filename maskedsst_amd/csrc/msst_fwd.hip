@@ -112,12 +112,15 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
     const elem* w2 = reinterpret_cast<const elem*>(a.w.w2);
     const TileMap tm = a.tm;
     const int L = tm.L;
+    const int2 sp_ln = tm.row_sp(tid >> 2);          // row handled in the LN1 phase
+    const int2 sp_ep = tm.row_sp(wave * 16 + c);     // row handled in the epilogue
+    const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;   // keys of the query row's own sequence
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         // ---------------- LN1 (4 threads per row, 24 features each) ----------------
         {
             const int r = tid >> 2, part = tid & 3;
-            const long tok = tm.token(tile, r);
+            const long tok = tm.token_sp(tile, sp_ln);
             float v[24];
             if (tok >= 0) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24);
@@ -190,14 +193,13 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
 #pragma unroll
                     for (int t = 0; t < 4; ++t) s[t] = P::mma(P::ld_kc(&sm.k[t * 16][k0], LDH), qb, s[t]);  // C[i = key][j = query]
                 }
-                const int qseq = (wave * 16 + c) / L;
                 float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = t * 16 + 4 * g + r;
-                        const float v = (key / L == qseq) ? s[t][r] * a.scale : -INFINITY;
+                        const float v = (key >= qlo && key < qhi) ? s[t][r] * a.scale : -INFINITY;
                         s[t][r] = v;
                         mx = fmaxf(mx, v);
                     }
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = expf(s[t][r] - mx);  // exp(-inf) = 0 for masked keys
+                        const float e = P::exp(s[t][r] - mx);  // exp(-inf) = 0 for masked keys
                         s[t][r] = e;
                         sum += e;
                     }
@@ -242,8 +244,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
         }
 
         // ---------------- residual + LN2 + MLP + residual (wave owns 16 rows) ----------------
-        const int row = wave * 16 + c;
-        const long tok = tm.token(tile, row);
+        const long tok = tm.token_sp(tile, sp_ep);
         float x1[6][4];
         float s1 = 0.f;
 #pragma unroll

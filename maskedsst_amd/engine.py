@@ -46,7 +46,7 @@ class Engine:
         self.prec = _prec_of(getattr(encoder, "precision", None))
         self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
         self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "256"))      # persistent grid of the row-wise bwd kernels
-        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "32"))  # x heads workgroups in the attention bwd
+        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "64"))  # x heads workgroups in the attention bwd
         self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "16"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self._wbuf = None
