@@ -148,6 +148,7 @@ int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * of HIP events recorded on the launch stream.  msst_profile_collect synchronises on the recorded
  * events and returns, per kernel id (0 .. msst_profile_kernels()-1), the summed duration in ms and
  * the launch count since enable / the previous collect.  Not thread-safe; meant for bench.py. */
+int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tools/stamps.py */);
 int msst_profile_enable(int on);
 int msst_profile_kernels(void);
 const char* msst_profile_name(int id);

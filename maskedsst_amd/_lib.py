@@ -54,6 +54,7 @@ _SIGS = {
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "msst_debug_stamps": (c_int, [_P]),
     "msst_profile_enable": (c_int, [c_int]),
     "msst_profile_kernels": (c_int, []),
     "msst_profile_name": (c_char_p, [c_int]),

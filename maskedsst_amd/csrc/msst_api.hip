@@ -2,6 +2,7 @@
 #include "../../include/msst.h"
 #include "msst_kernels.h"
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <vector>
 
@@ -31,7 +32,16 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
             src_i = r * j.cols + c;
         }
         const float v = j.src[src_i];
-        if constexpr (sizeof(E) == 4) dst[i] = v; else dst[i] = f2bf(v);
+        if constexpr (sizeof(E) == 4) {
+            dst[i] = v;
+        } else {
+            // fragment-packed destination (see PBF16::ld_w): logical (r, c) of the [R][K] destination matrix
+            const int K = j.transpose ? j.rows : j.cols;
+            const int r = i / K, c = i - r * K;
+            const int f = (r >> 4) * (K >> 5) + (c >> 5);
+            const int lane = ((c & 31) >> 3) * 16 + (r & 15);
+            dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+        }
     }
 }
 
@@ -39,6 +49,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
 // opt-in profiler: a pair of HIP events around each kernel launch, on the launch stream
 // ------------------------------------------------------------------------------------------
 struct ProfRec { int id; hipEvent_t a, b; };
+static unsigned long long* g_stamps = nullptr;
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
@@ -98,6 +109,8 @@ extern "C" {
 
 int msst_version(void) { return MSST_VERSION; }
 const char* msst_last_error(void) { return g_err; }
+
+int msst_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return 0; }
 
 int msst_profile_enable(int on) {
     g_prof_on = on != 0;
@@ -163,6 +176,9 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.max_grid = max_grid > 0 ? max_grid : a.ntiles;
     a.H = heads;
     a.scale = 0.125f;  // dim_head ** -0.5, dim_head = 64 (vit_spatial_spectral.py:54)
+    { const char* e = getenv("MSST_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.stamps = g_stamps;
+    if (!g_stamps) a.dbg &= ~8;
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 

@@ -178,8 +178,8 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             const frag db = P::ld_kc(&sm.dy[wave * 16][k0], LDX);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                hp[nt] = P::mma(P::ld_kc(w1 + (long)(nt * 16) * 96 + k0, 96), xb, hp[nt]);
-                dh[nt] = P::mma(P::ld_kc(w2T + (long)(nt * 16) * 96 + k0, 96), db, dh[nt]);
+                hp[nt] = P::mma(P::ld_w(w1, 96, nt * 16, k0), xb, hp[nt]);
+                dh[nt] = P::mma(P::ld_w(w2T, 96, nt * 16, k0), db, dh[nt]);
             }
         }
 #pragma unroll
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int k0 = 0; k0 < 64; k0 += KS) {
             const frag hb = P::ld_kc(&sm.dhp[wave * 16][k0], LDH);
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(P::ld_kc(w1T + (long)(mt * 16) * 64 + k0, 64), hb, dxn[mt]);
+            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(P::ld_w(w1T, 64, mt * 16, k0), hb, dxn[mt]);
         }
         // LN2 backward + residual
         float g1 = 0.f, g2 = 0.f;
@@ -390,14 +390,12 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             f32x4 cq[4], ck[4], cv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
-            const elem* wq = wqkv + (long)((0 * H + h) * 64 + wave * 16) * 96;
-            const elem* wk = wqkv + (long)((1 * H + h) * 64 + wave * 16) * 96;
-            const elem* wv = wqkv + (long)((2 * H + h) * 64 + wave * 16) * 96;
+            const int rq = (0 * H + h) * 64 + wave * 16, rk = (1 * H + h) * 64 + wave * 16, rv = (2 * H + h) * 64 + wave * 16;
 #pragma unroll P::UNROLL
             for (int k0 = 0; k0 < 96; k0 += KS) {
-                const frag aq = P::ld_kc(wq + k0, 96);
-                const frag ak = P::ld_kc(wk + k0, 96);
-                const frag av = P::ld_kc(wv + k0, 96);
+                const frag aq = P::ld_w(wqkv, 96, rq, k0);
+                const frag ak = P::ld_w(wqkv, 96, rk, k0);
+                const frag av = P::ld_w(wqkv, 96, rv, k0);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     const frag xb = P::ld_kc(&sm.xd[t * 16][k0], LDX);
@@ -478,7 +476,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
-                    dov[t] = P::mma(P::ld_kc(woutT + (long)(h * 64 + t * 16) * 96 + k0, 96), db, dov[t]);
+                    dov[t] = P::mma(P::ld_w(woutT, 96, h * 64 + t * 16, k0), db, dov[t]);
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -573,10 +571,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 const frag bv = P::ld_kc(&sm.vt[wave * 16][k0], LDH);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    const elem* wt = wqkvT + (long)(t * 16) * (3 * inner) + h * 64 + k0;
-                    dx[t] = P::mma(P::ld_kc(wt, 3 * inner), bq, dx[t]);
-                    dx[t] = P::mma(P::ld_kc(wt + inner, 3 * inner), bk, dx[t]);
-                    dx[t] = P::mma(P::ld_kc(wt + 2 * inner, 3 * inner), bv, dx[t]);
+                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, h * 64 + k0), bq, dx[t]);
+                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, inner + h * 64 + k0), bk, dx[t]);
+                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, 2 * inner + h * 64 + k0), bv, dx[t]);
                 }
             }
             // stage the [16 x 96] result rows of this wave in xd (dead now) and write whole rows

@@ -64,6 +64,10 @@ struct PF32 {
         const int l = lane_id();
         return p[(l >> 4) * ld + (l & 15)];
     }
+    // global weight fragment: rows row0..+15, k-slice starting at k0 of a [R][K] matrix (fp32: row-major)
+    static __device__ __forceinline__ frag ld_w(const elem* w, int K, int row0, int k0) {
+        return ld_kc(w + (long)row0 * K + k0, K);
+    }
     // natural store of a C tile: OUT[j][i0..i0+3], p -> OUT[j0][i0]
     static __device__ __forceinline__ void st_nat(elem* p, int ld, f32x4 c) {
         const int l = lane_id();
@@ -97,6 +101,13 @@ struct PBF16 {
         const int l = lane_id();
         return *reinterpret_cast<const s16x8*>(p + (l & 15) * ld + 8 * (l >> 4));
     }
+    // global weight fragment of a [R][K] matrix.  bf16 weights are stored FRAGMENT-PACKED by
+    // msst_prep_weights: the 1 KB fragment (16 rows x 32 k) f = (row0/16)*(K/32) + k0/32 is contiguous
+    // in lane order, so one global_load_dwordx4 per lane reads 8 full cache lines instead of 16 halves.
+    static __device__ __forceinline__ frag ld_w(const elem* w, int K, int row0, int k0) {
+        const int f = (row0 >> 4) * (K >> 5) + (k0 >> 5);
+        return *reinterpret_cast<const s16x8*>(w + ((long)f * 64 + lane_id()) * 8);
+    }
     // k-strided operand in LDS: element (row, k) at p[k*ld + row].  Two ds_read_b64_tr_b16: the 16
     // lanes of a group fetch a [4 k][16 row] block (lane i supplies the address of k-row i>>2,
     // column chunk (i&3)*4) and each receives column i = its 4 consecutive-k values
@@ -126,15 +137,20 @@ struct PBF16 {
 // ------------------------------------------------------------------------------------------
 // reductions over the 4 lane groups that share one C-fragment column (lanes l, l^16, l^32, l^48)
 // ------------------------------------------------------------------------------------------
+// v_permlane16_swap / v_permlane32_swap (gfx950): with vdst == src == v the two results are
+// (even rows | even rows) and (odd rows | odd rows) resp. (low half | low half), (high | high), so
+// their sum / max equals v (+) shfl_xor(v, 16 / 32) on every lane -- VALU only, no LDS round trip.
 __device__ __forceinline__ float colgroup_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    return v;
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ float colgroup_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 16));
-    v = fmaxf(v, __shfl_xor(v, 32));
-    return v;
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // reduction over the 16 lanes that share one lane group (lanes with equal lane>>4)
 __device__ __forceinline__ float rowgroup_sum(float v) {
@@ -151,6 +167,12 @@ __device__ __forceinline__ float gelu_erf_grad(float x) {
     const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
+}
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt(0), which
+// would serialise the global prefetches that are deliberately left in flight across phases.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }

@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
 // phase B (wave <-> 16 query rows): S^T = k q^T, masked softmax over keys in registers, P -> LDS,
 // O = P v, out-projection accumulated in registers across heads.  Then residual, LN2, MLP, residual.
 // ==========================================================================================
+#define STAMP(i) do { if (stamp_on) { a.stamps[(i)] = __builtin_readcyclecounter(); } } while (0)
+
 template <class P>
 struct FwdSmem {
     typedef typename P::elem elem;
@@ -116,7 +118,10 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
     const int2 sp_ep = tm.row_sp(wave * 16 + c);     // row handled in the epilogue
     const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;   // keys of the query row's own sequence
 
+    const bool stamp_on = (a.dbg & 8) && blockIdx.x == (unsigned)(a.ntiles / 2) && tid == 0;
+
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        STAMP(0);
         // ---------------- LN1 (4 threads per row, 24 features each) ----------------
         {
             const int r = tid >> 2, part = tid & 3;
@@ -146,26 +151,28 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 sm.xn[r][d] = P::cvt((v[i] - mean) * rstd * a.w.ln1_g[d] + a.w.ln1_b[d]);
             }
         }
+        STAMP(1);
         __syncthreads();
+        STAMP(2);
 
         f32x4 oacc[6];
 #pragma unroll
         for (int i = 0; i < 6; ++i) oacc[i] = zero4();
 
         for (int h = 0; h < H; ++h) {
+            STAMP(3 + h * 8);
             // ---------------- phase A: q, k, v^T for head h ----------------
             {
                 f32x4 cq[4], ck[4], cv[4];
 #pragma unroll
                 for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
-                const elem* wq = wqkv + (long)((0 * H + h) * 64 + wave * 16) * 96;
-                const elem* wk = wqkv + (long)((1 * H + h) * 64 + wave * 16) * 96;
-                const elem* wv = wqkv + (long)((2 * H + h) * 64 + wave * 16) * 96;
+                const int hw = (a.dbg & 1) ? 0 : h;   // ablation: all heads read the same (L1-resident) weights
+                const int rq = (0 * H + hw) * 64 + wave * 16, rk = (1 * H + hw) * 64 + wave * 16, rv = (2 * H + hw) * 64 + wave * 16;
 #pragma unroll P::UNROLL
                 for (int k0 = 0; k0 < 96; k0 += KS) {
-                    const frag aq = P::ld_kc(wq + k0, 96);
-                    const frag ak = P::ld_kc(wk + k0, 96);
-                    const frag av = P::ld_kc(wv + k0, 96);
+                    const frag aq = P::ld_w(wqkv, 96, rq, k0);
+                    const frag ak = P::ld_w(wqkv, 96, rk, k0);
+                    const frag av = P::ld_w(wqkv, 96, rv, k0);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const frag xb = P::ld_kc(&sm.xn[t * 16][k0], LDX);
@@ -181,7 +188,9 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                     P::st_nat(&sm.vt[wave * 16][t * 16], LDH, cv[t]);  // vt[d][row]
                 }
             }
-            __syncthreads();
+            STAMP(4 + h * 8);
+            if (!(a.dbg & 2)) __syncthreads();
+            STAMP(5 + h * 8);
             // ---------------- phase B: attention for query rows wave*16 .. +15 ----------------
             {
                 f32x4 s[4];
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float e = P::exp(s[t][r] - mx);  // exp(-inf) = 0 for masked keys
+                        const float e = (a.dbg & 4) ? (s[t][r] > -1e30f ? 1.f : 0.f) : P::exp(s[t][r] - mx);  // exp(-inf) = 0 for masked keys
                         s[t][r] = e;
                         sum += e;
                     }
@@ -217,6 +226,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 const float inv = 1.f / sum;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) P::st_nat(&sm.p[wave * 16][t * 16], LDH, s[t] * inv);  // p[query][key]
+                STAMP(6 + h * 8);
                 __builtin_amdgcn_wave_barrier();
                 f32x4 o[4];
 #pragma unroll
@@ -230,6 +240,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 // O over this wave's (now dead) q rows: o[query][d]
 #pragma unroll
                 for (int t = 0; t < 4; ++t) P::st_nat(&sm.q[wave * 16][t * 16], LDH, o[t]);
+                STAMP(7 + h * 8);
                 __builtin_amdgcn_wave_barrier();
                 // out-projection, accumulated over heads: C[i = m][j = query], A = Wout[m][h*64 + d]
 #pragma unroll P::UNROLL
@@ -237,11 +248,14 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                     const frag ob = P::ld_kc(&sm.q[wave * 16][k0], LDH);
 #pragma unroll
                     for (int mt = 0; mt < 6; ++mt)
-                        oacc[mt] = P::mma(P::ld_kc(wout + (long)(mt * 16) * inner + h * 64 + k0, inner), ob, oacc[mt]);
+                        oacc[mt] = P::mma(P::ld_w(wout, inner, mt * 16, ((a.dbg & 1) ? 0 : h * 64) + k0), ob, oacc[mt]);
                 }
             }
-            __syncthreads();
+            STAMP(8 + h * 8);
+            if (!(a.dbg & 2)) __syncthreads();
+            STAMP(9 + h * 8);
         }
+        STAMP(3 + H * 8);
 
         // ---------------- residual + LN2 + MLP + residual (wave owns 16 rows) ----------------
         const long tok = tm.token_sp(tile, sp_ep);
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
         for (int k0 = 0; k0 < 96; k0 += KS) {
             const frag xb = P::ld_kc(&sm.xn[wave * 16][k0], LDX);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(P::ld_kc(w1 + (long)(nt * 16) * 96 + k0, 96), xb, hh[nt]);  // C[i = n][j = row]
+            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(P::ld_w(w1, 96, nt * 16, k0), xb, hh[nt]);  // C[i = n][j = row]
         }
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
         for (int k0 = 0; k0 < 64; k0 += KS) {
             const frag hb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(P::ld_kc(w2 + (long)(mt * 16) * 64 + k0, 64), hb, yy[mt]);  // C[i = m][j = row]
+            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(P::ld_w(w2, 64, mt * 16, k0), hb, yy[mt]);  // C[i = m][j = row]
         }
         if (tok >= 0) {
 #pragma unroll
@@ -316,7 +330,297 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
             }
         }
+        STAMP(4 + H * 8);
         __syncthreads();
+        STAMP(5 + H * 8);
+    }
+}
+
+
+// ==========================================================================================
+// bf16 throughput variant of block_fwd: same math and LDS layout as block_fwd_kernel<PBF16>, but
+// (1) every global operand of a phase is fetched into registers one phase AHEAD (the measured
+// global-load round trip is ~2k cycles under load: per-head weights for phase A are requested when
+// the previous head's phase A retires them, the out-projection slice at the start of phase B, the
+// MLP weights at the start of the epilogue, the next tile's rows during the current tile), and
+// (2) the grid is persistent (2 workgroups per CU walk the tiles).
+// ==========================================================================================
+__global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
+    typedef PBF16 P;
+    typedef bf16_t elem;
+    typedef s16x8 frag;
+    typedef FwdSmem<P> SM;
+    constexpr int LDX = SM::LDX, LDH = SM::LDH;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int H = a.H, inner = H * 64;
+    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
+    const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
+    const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
+    const elem* w2 = reinterpret_cast<const elem*>(a.w.w2);
+    const TileMap tm = a.tm;
+    const int L = tm.L;
+    const int2 sp_ln = tm.row_sp(tid >> 2);
+    const int2 sp_ep = tm.row_sp(wave * 16 + c);
+    const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;
+    const int part = tid & 3, lr = tid >> 2;
+
+    // LN1 gamma/beta live in LDS (tile invariant; keeps 48 registers free)
+    // small parameter vectors live in LDS (tile invariant; no dependent global loads in the tile loop)
+    float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));   // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1
+    if (tid < 96) {
+        lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; lnp[192 + tid] = a.w.bo[tid];
+        lnp[288 + tid] = a.w.ln2_g[tid]; lnp[384 + tid] = a.w.ln2_b[tid]; lnp[480 + tid] = a.w.b2[tid];
+        if (tid < 64) lnp[576 + tid] = a.w.b1[tid];
+    }
+    __syncthreads();
+
+    // rows of the first tile
+    f32x4 xv[6];
+    {
+        const long tok = tm.token_sp(blockIdx.x, sp_ln);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xv[i] = tok >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24)[i] : zero4();
+    }
+
+    const bool stamp_on = (a.dbg & 8) && blockIdx.x == 100 && tid == 0;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        STAMP(0);
+        // phase-A weights of head 0 (q, k, v rows of this wave's 16 channels; 3 k-steps each)
+        frag wa[3][3];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                wa[m][ks] = P::ld_w(wqkv, 96, (m * H + 0) * 64 + wave * 16, ks * 32);
+        // ---------------- LN1 from the prefetched rows ----------------
+        {
+            float v[24];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) s += v[i];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            const float mean = s * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[part * 24 + 4*i+e] + lnp[96 + part * 24 + 4*i+e];
+                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 24 + 4 * i]) = f2bf4(n4);
+            }
+        }
+        STAMP(1);
+        lds_barrier();
+        STAMP(2);
+
+        f32x4 oacc[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) oacc[i] = zero4();
+        const long tok = tm.token_sp(tile, sp_ep);
+        f32x4 xres[6];   // residual rows in C layout, requested during the last head
+
+        for (int h = 0; h < H; ++h) {
+            STAMP(3 + h * 8);
+            // ---------------- phase A ----------------
+            {
+                f32x4 cq[4], ck[4], cv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag xb = P::ld_kc(&sm.xn[t * 16][ks * 32], LDX);
+                        cq[t] = P::mma(wa[0][ks], xb, cq[t]);
+                        ck[t] = P::mma(wa[1][ks], xb, ck[t]);
+                        cv[t] = P::mma(xb, wa[2][ks], cv[t]);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    P::st_nat(&sm.q[t * 16][wave * 16], LDH, cq[t]);
+                    P::st_nat(&sm.k[t * 16][wave * 16], LDH, ck[t]);
+                    P::st_nat(&sm.vt[wave * 16][t * 16], LDH, cv[t]);
+                }
+            }
+            STAMP(4 + h * 8);
+            // requests for later phases: this head's out-projection slice, the next head's phase A
+            frag wo[6][2];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    wo[mt][ks] = P::ld_w(wout, inner, mt * 16, h * 64 + ks * 32);
+            if (h + 1 < H) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks)
+                        wa[m][ks] = P::ld_w(wqkv, 96, (m * H + h + 1) * 64 + wave * 16, ks * 32);
+            } else {
+                // last head: wa is free -> request the residual rows (C layout) and the NEXT tile's rows
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt)
+                    xres[mt] = tok >= 0 ? *reinterpret_cast<const f32x4*>(a.x + tok * 96 + mt * 16 + 4 * g) : zero4();
+                const int nt = tile + gridDim.x;
+                const long tokn = nt < a.ntiles ? tm.token_sp(nt, sp_ln) : -1;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + part * 24)[i] : zero4();
+            }
+            lds_barrier();
+            STAMP(5 + h * 8);
+            // ---------------- phase B ----------------
+            {
+                f32x4 s[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) s[t] = zero4();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const frag qb = P::ld_kc(&sm.q[wave * 16][ks * 32], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) s[t] = P::mma(P::ld_kc(&sm.k[t * 16][ks * 32], LDH), qb, s[t]);
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * 16 + 4 * g + r;
+                        const float v = (key >= qlo && key < qhi) ? s[t][r] * a.scale : -INFINITY;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = colgroup_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - mx); s[t][r] = e; sum += e; }
+                sum = colgroup_sum(sum);
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P::st_nat(&sm.p[wave * 16][t * 16], LDH, s[t] * inv);
+                STAMP(6 + h * 8);
+                __builtin_amdgcn_wave_barrier();
+                f32x4 o[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) o[t] = zero4();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const frag pb = P::ld_kc(&sm.p[wave * 16][ks * 32], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][ks * 32], LDH), pb, o[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) P::st_nat(&sm.q[wave * 16][t * 16], LDH, o[t]);
+                STAMP(7 + h * 8);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const frag ob = P::ld_kc(&sm.q[wave * 16][ks * 32], LDH);
+#pragma unroll
+                    for (int mt = 0; mt < 6; ++mt) oacc[mt] = P::mma(wo[mt][ks], ob, oacc[mt]);
+                }
+            }
+            STAMP(8 + h * 8);
+            lds_barrier();
+            STAMP(9 + h * 8);
+        }
+        STAMP(3 + H * 8);
+
+        // ---------------- epilogue: residual, LN2, MLP, residual ----------------
+        frag w1f[4][3];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+                w1f[nt][ks] = P::ld_w(w1, 96, nt * 16, ks * 32);
+        float x1[6][4];
+        float s1 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                x1[mt][r] = oacc[mt][r] + lnp[192 + m0 + r] + xres[mt][r];
+                o4[r] = x1[mt][r];
+                s1 += x1[mt][r];
+            }
+            if (a.x1 && tok >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+        }
+        s1 = colgroup_sum(s1);
+        const float mean = s1 * (1.f / 96.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = x1[mt][r] - mean; vs += d * d; }
+        vs = colgroup_sum(vs);
+        const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int m0 = mt * 16 + 4 * g;
+            f32x4 n4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) n4[r] = (x1[mt][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
+            P::st_nat(&sm.xn[wave * 16][mt * 16], LDX, n4);
+        }
+        frag w2f[6][2];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                w2f[mt][ks] = P::ld_w(w2, 64, mt * 16, ks * 32);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 hh[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) hh[nt] = zero4();
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const frag xb = P::ld_kc(&sm.xn[wave * 16][ks * 32], LDX);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(w1f[nt][ks], xb, hh[nt]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int n0 = nt * 16 + 4 * g;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_erf(hh[nt][r] + lnp[576 + n0 + r]);
+            P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 yy[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) yy[mt] = zero4();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const frag hb = P::ld_kc(&sm.p[wave * 16][ks * 32], LDH);
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(w2f[mt][ks], hb, yy[mt]);
+        }
+        if (tok >= 0) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int m0 = mt * 16 + 4 * g;
+                f32x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + lnp[480 + m0 + r] + x1[mt][r];
+                *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+            }
+        }
+        STAMP(4 + H * 8);
+        lds_barrier();
+        STAMP(5 + H * 8);
     }
 }
 
@@ -410,11 +714,31 @@ static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
     return (int)hipGetLastError();
 }
 
+static int launch_block_fwd_bf16(const BlockArgs& a, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(FwdSmem<PBF16>) + 640 * sizeof(float);
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_bf16_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ProfScope ps(K_BLOCK_FWD, st);
+    hipLaunchKernelGGL(block_fwd_bf16_kernel, dim3(grid), dim3(256), smem, st, a);
+    return (int)hipGetLastError();
+}
+
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
-    int grid = a.ntiles < a.max_grid ? a.ntiles : a.max_grid;
-    if (grid < 1) return 0;
-    return prec == MSST_PREC_F32 ? launch_block_fwd_t<PF32>(a, grid, st) : launch_block_fwd_t<PBF16>(a, grid, st);
+    if (a.ntiles < 1) return 0;
+    if (prec == MSST_PREC_F32 || (a.dbg & 16)) {   // dbg 16: generic template also for bf16 (A/B studies)
+        const int grid = a.ntiles < a.max_grid ? a.ntiles : a.max_grid;
+        return prec == MSST_PREC_F32 ? launch_block_fwd_t<PF32>(a, grid, st) : launch_block_fwd_t<PBF16>(a, grid, st);
+    }
+    // persistent grid: 2 workgroups per CU (LDS 50 KB, <= 256 VGPRs)
+    int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
+    if (grid > 512) grid = 512;
+    return launch_block_fwd_bf16(a, grid, st);
 }
 
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {

@@ -34,6 +34,8 @@ struct BlockArgs {
     TileMap tm;
     int ntiles, max_grid, H;
     float scale;      // dim_head^-0.5
+    int dbg;          // ablation switches for kernel studies (0 in production)
+    unsigned long long* stamps;  // dbg & 8: s_memtime stamps of one wave (kernel studies)
 };
 
 struct TokArgs {
