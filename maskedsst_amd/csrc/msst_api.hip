@@ -244,6 +244,9 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     {
         aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f;
+        { const char* e = getenv("MSST_DBG"); aa.dbg = e ? atoi(e) : 0; }
+        aa.stamps = g_stamps;
+        if (!g_stamps) aa.dbg &= ~8;
         int rc = launch_block_bwd_attn(aa, nc, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(attn)");
     }

@@ -381,27 +381,130 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
     for (int it = 0; it < (16 * CPR) / 64; ++it) sp_out[it] = tm.row_sp(wave * 16 + (it * 64 + l) / CPR);
 
+    const bool stamp_on = (a.dbg & 8) && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0;
+    // bf16: software prefetch (global round trips are ~2k cycles under load); fp32 keeps the simple loads
+    // (measured: prefetching rows + da + both weight sets needs ~400 registers -> 1 workgroup/CU, slower than
+    // 2 workgroups/CU without it; only the cheap parts are enabled)
+    constexpr bool BF = sizeof(elem) == 2;
+    constexpr bool PF = false;          // rows / da / weight-fragment prefetch into registers
+    constexpr bool KEEP_XN = BF;        // keep LN1(x) packed (12 registers) instead of recomputing it for phase D
+    constexpr int NKX = PF ? 3 : 1, NKD = PF ? 3 : 1;
+    // LN1 gamma / beta in LDS (tile invariant)
+    float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));
+    if (tid < 96) { lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; }
+    __syncthreads();
+    const int lr = tid >> 2, lpart = tid & 3;
+    f32x4 xv[6];          // this thread's 24 row values of the tile to process (prefetched one tile ahead)
+    if constexpr (PF) {
+        const long tok0 = tm.token_sp(blockIdx.x, sp_ln);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xv[i] = tok0 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok0 * 96 + lpart * 24)[i] : zero4();
+    }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        STAMP(0);
         const long tok_ln = tm.token_sp(tile, sp_ln);
-        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tok_ln, sm.xd);
-        __syncthreads();
+        f32x4 dav[6];         // da rows of this tile (consumed after phase A)
+        frag wa[3][NKX];      // phase-A weight fragments
+        s16x4 xnk[6];         // LN1(x) of this thread's 24 features, packed bf16 (re-stored before phase D)
+        if constexpr (PF) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dav[i] = tok_ln >= 0 ? reinterpret_cast<const f32x4*>(a.da + tok_ln * 96 + lpart * 24)[i] : zero4();
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int ks = 0; ks < NKX; ++ks) wa[m][ks] = P::ld_w(wqkv, 96, (m * H + h) * 64 + wave * 16, ks * 32);
+            // LN1 from the prefetched rows
+            float v[24];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+            float sm1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) sm1 += v[i];
+            sm1 += __shfl_xor(sm1, 1); sm1 += __shfl_xor(sm1, 2);
+            const float mean = sm1 * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = lpart * 24 + 4 * i + e;
+                    n4[e] = (v[4*i+e] - mean) * rstd * lnp[d] + lnp[96 + d];
+                }
+                xnk[i] = f2bf4(n4);
+                *reinterpret_cast<s16x4*>(&sm.xd[lr][lpart * 24 + 4 * i]) = xnk[i];
+            }
+        } else if constexpr (KEEP_XN) {
+            float v[24];
+            if (tok_ln >= 0) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok_ln * 96 + lpart * 24);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 24; ++i) v[i] = 0.f;
+            }
+            float sm1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) sm1 += v[i];
+            sm1 += __shfl_xor(sm1, 1); sm1 += __shfl_xor(sm1, 2);
+            const float mean = sm1 * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int d = lpart * 24 + 4 * i + e;
+                    n4[e] = (v[4*i+e] - mean) * rstd * lnp[d] + lnp[96 + d];
+                }
+                xnk[i] = f2bf4(n4);
+                *reinterpret_cast<s16x4*>(&sm.xd[lr][lpart * 24 + 4 * i]) = xnk[i];
+            }
+        } else {
+            ln1_rows_to_lds<P>(a.x, lnp, lnp + 96, tok_ln, sm.xd);
+        }
+        STAMP(1);
+        lds_barrier();
+        STAMP(2);
         // ---------------- phase A: q, k, v^T (wave <-> 16 head channels) ----------------
         {
             f32x4 cq[4], ck[4], cv[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
             const int rq = (0 * H + h) * 64 + wave * 16, rk = (1 * H + h) * 64 + wave * 16, rv = (2 * H + h) * 64 + wave * 16;
-#pragma unroll P::UNROLL
-            for (int k0 = 0; k0 < 96; k0 += KS) {
-                const frag aq = P::ld_w(wqkv, 96, rq, k0);
-                const frag ak = P::ld_w(wqkv, 96, rk, k0);
-                const frag av = P::ld_w(wqkv, 96, rv, k0);
+            if constexpr (PF) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const frag xb = P::ld_kc(&sm.xd[t * 16][k0], LDX);
-                    cq[t] = P::mma(aq, xb, cq[t]);
-                    ck[t] = P::mma(ak, xb, ck[t]);
-                    cv[t] = P::mma(xb, av, cv[t]);
+                for (int ks = 0; ks < NKX; ++ks) {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag xb = P::ld_kc(&sm.xd[t * 16][ks * 32], LDX);
+                        cq[t] = P::mma(wa[0][ks], xb, cq[t]);
+                        ck[t] = P::mma(wa[1][ks], xb, ck[t]);
+                        cv[t] = P::mma(xb, wa[2][ks], cv[t]);
+                    }
+                }
+            } else {
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 96; k0 += KS) {
+                    const frag aq = P::ld_w(wqkv, 96, rq, k0);
+                    const frag ak = P::ld_w(wqkv, 96, rk, k0);
+                    const frag av = P::ld_w(wqkv, 96, rv, k0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag xb = P::ld_kc(&sm.xd[t * 16][k0], LDX);
+                        cq[t] = P::mma(aq, xb, cq[t]);
+                        ck[t] = P::mma(ak, xb, ck[t]);
+                        cv[t] = P::mma(xb, av, cv[t]);
+                    }
                 }
             }
 #pragma unroll
@@ -411,7 +514,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 P::st_nat(&sm.vt[wave * 16][t * 16], LDH, cv[t]);
             }
         }
-        __syncthreads();
+        STAMP(3);
+        lds_barrier();
+        STAMP(4);
         // ---------------- da rows -> xd (overwrites LN1(x); rows of this wave only) ----------------
         {
             const int r = tid >> 2, pt = tid & 3;
@@ -419,10 +524,18 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 f32x4 t4 = zero4();
-                if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
+                if constexpr (PF) t4 = dav[i];
+                else if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sm.xd[r][pt * 24 + 4 * i + e] = P::cvt(t4[e]);
             }
+        }
+        frag wdo[4][NKD];   // Wout_h^T fragments for the dO GEMM (requested now, used after S / softmax / O)
+        if constexpr (PF) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < NKD; ++ks) wdo[t][ks] = P::ld_w(woutT, 96, h * 64 + t * 16, ks * 32);
         }
         // ---------------- phase B: wave <-> 16 query rows ----------------
         f32x4 pr[4];
@@ -459,6 +572,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 P::st_nat(&sm.p[wave * 16][t * 16], LDH, pr[t]);  // p[query][key]
             }
         }
+        STAMP(5);
         __builtin_amdgcn_wave_barrier();
         {
             // o = P v  (C[i = d][j = query]) and dO = Wout_h^T da (C[i = d][j = query])
@@ -471,12 +585,21 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);
             }
-#pragma unroll P::UNROLL
-            for (int k0 = 0; k0 < 96; k0 += KS) {
-                const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
+            if constexpr (PF) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dov[t] = P::mma(P::ld_w(woutT, 96, h * 64 + t * 16, k0), db, dov[t]);
+                for (int ks = 0; ks < NKD; ++ks) {
+                    const frag db = P::ld_kc(&sm.xd[wave * 16][ks * 32], LDX);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dov[t] = P::mma(wdo[t][ks], db, dov[t]);
+                }
+            } else {
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 96; k0 += KS) {
+                    const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        dov[t] = P::mma(P::ld_w(woutT, 96, h * 64 + t * 16, k0), db, dov[t]);
+                }
             }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -484,6 +607,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 P::st_nat(&sm.dO[wave * 16][t * 16], LDH, dov[t]);   // dO[query][d]
             }
         }
+        STAMP(6);
         __builtin_amdgcn_wave_barrier();
         {
             // dP^T[key][query] = sum_d v[key][d] dO[query][d]: A = v (k-strided read of vt), B = dO rows
@@ -510,8 +634,16 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 P::st_nat(&sm.ds[wave * 16][t * 16], LDH, d4);  // ds[query][key]
             }
         }
-        __syncthreads();
+        STAMP(7);
+        lds_barrier();
+        STAMP(8);
         // ---------------- phase C: contractions over all 64 queries / keys ----------------
+        if constexpr (PF) {   // rows of the NEXT tile of this workgroup
+            const int nt = tile + gridDim.x;
+            const long tokn = nt < a.ntiles ? tm.token_sp(nt, sp_ln) : -1;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + lpart * 24)[i] : zero4();
+        }
         f32x4 dq[4], dk[4], dv[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) { dq[t] = zero4(); dk[t] = zero4(); dv[t] = zero4(); }
@@ -534,7 +666,21 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 dq[t] = P::mma(P::ld_ks(&sm.k[k0][t * 16], LDH), sq, dq[t]);
             }
         }
-        __syncthreads();
+        STAMP(9);
+        lds_barrier();
+        STAMP(10);
+        if constexpr (sizeof(elem) == 2) {
+            // bf16: stage this head's 36 wqkvT fragments (all four waves need all of them in the
+            // d(LN1 out) GEMM) into the dead p|dO|ds|o region with async global->LDS copies, 9 per wave
+            char* stage = reinterpret_cast<char*>(&sm.p[0][0]);
+#pragma unroll
+            for (int i9 = 0; i9 < 9; ++i9) {
+                const int idx = wave * 9 + i9;                    // idx = (t * 3 + which) * 2 + ks
+                const int t = idx / 6, which = (idx >> 1) % 3, ks = idx & 1;
+                const int f = t * ((3 * inner) >> 5) + ((which * inner + h * 64 + ks * 32) >> 5);
+                dma_frag(wqkvT + (long)f * 512, stage + idx * 1024);
+            }
+        }
         // dq / dk / dv over the dead q / k / vt buffers, all as [row][d]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -542,8 +688,15 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             P::st_nat(&sm.k[wave * 16][t * 16], LDH, dk[t]);
             P::st_nat(&sm.vt[wave * 16][t * 16], LDH, dv[t]);
         }
-        ln1_rows_to_lds<P>(a.x, a.w.ln1_g, a.w.ln1_b, tok_ln, sm.xd);
-        __syncthreads();
+        if constexpr (PF || KEEP_XN) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) *reinterpret_cast<s16x4*>(&sm.xd[lr][lpart * 24 + 4 * i]) = xnk[i];
+        } else {
+            ln1_rows_to_lds<P>(a.x, lnp, lnp + 96, tok_ln, sm.xd);
+        }
+        STAMP(11);
+        lds_barrier();
+        STAMP(12);
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
 #pragma unroll P::UNROLL
         for (int k0 = 0; k0 < 64; k0 += KS) {
@@ -564,6 +717,10 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             f32x4 dx[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) dx[t] = zero4();
+            STAMP(13);
+            if constexpr (sizeof(elem) == 2) wait_vm0();   // this wave's staged fragments have landed
+            lds_barrier();
+            STAMP(14);   // every wave is done reading xd (weight-grad loop above); staged weights visible
 #pragma unroll P::UNROLL
             for (int k0 = 0; k0 < 64; k0 += KS) {
                 const frag bq = P::ld_kc(&sm.q[wave * 16][k0], LDH);
@@ -571,13 +728,21 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 const frag bv = P::ld_kc(&sm.vt[wave * 16][k0], LDH);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, h * 64 + k0), bq, dx[t]);
-                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, inner + h * 64 + k0), bk, dx[t]);
-                    dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, 2 * inner + h * 64 + k0), bv, dx[t]);
+                    if constexpr (sizeof(elem) == 2) {
+                        const char* stage = reinterpret_cast<const char*>(&sm.p[0][0]) + l * 16;
+                        const int ks = k0 >> 5;
+                        dx[t] = P::mma(*reinterpret_cast<const frag*>(stage + ((t * 3 + 0) * 2 + ks) * 1024), bq, dx[t]);
+                        dx[t] = P::mma(*reinterpret_cast<const frag*>(stage + ((t * 3 + 1) * 2 + ks) * 1024), bk, dx[t]);
+                        dx[t] = P::mma(*reinterpret_cast<const frag*>(stage + ((t * 3 + 2) * 2 + ks) * 1024), bv, dx[t]);
+                    } else {
+                        dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, h * 64 + k0), bq, dx[t]);
+                        dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, inner + h * 64 + k0), bk, dx[t]);
+                        dx[t] = P::mma(P::ld_w(wqkvT, 3 * inner, t * 16, 2 * inner + h * 64 + k0), bv, dx[t]);
+                    }
                 }
             }
+            STAMP(15);
             // stage the [16 x 96] result rows of this wave in xd (dead now) and write whole rows
-            __syncthreads();   // every wave is done reading xd (weight-grad loop above)
 #pragma unroll
             for (int t = 0; t < 6; ++t) P::st_nat(&sm.xd[wave * 16][t * 16], LDX, dx[t]);
             __builtin_amdgcn_wave_barrier();
@@ -591,6 +756,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 }
             }
         }
+        STAMP(16);
         // no block barrier here: the next tile's LN1 only writes this wave's own xd rows, and q/k/vt
         // are not touched before the barrier that follows it
     }
@@ -923,13 +1089,13 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     dim3 grid(nchunk, a.H);
     if (prec == MSST_PREC_F32) {
-        const size_t smem = sizeof(AttnBwdSmem<PF32>);
+        const size_t smem = sizeof(AttnBwdSmem<PF32>) + 192 * sizeof(float);
         int rc = set_smem(&block_bwd_attn_kernel<PF32>, smem, d0);
         if (rc) return rc;
         ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
     } else {
-        const size_t smem = sizeof(AttnBwdSmem<PBF16>);
+        const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float);
         int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);
         if (rc) return rc;
         ProfScope ps(K_BWD_ATTN, st);

@@ -175,6 +175,17 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// async global -> LDS copy of one 1 KB fragment-packed weight fragment (16 B per lane, LDS image is
+// lane-linear = exactly the packed layout).  Completion is tracked by vmcnt.
+__device__ __forceinline__ void dma_frag(const void* gsrc_frag, void* lds_dst_frag) {
+    const char* src = reinterpret_cast<const char*>(gsrc_frag) + lane_id() * 16;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst_frag, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+#define STAMP(i) do { if (stamp_on) { a.stamps[(i)] = __builtin_readcyclecounter(); } } while (0)
+
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
 
 // ------------------------------------------------------------------------------------------

@@ -83,8 +83,6 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
 // phase B (wave <-> 16 query rows): S^T = k q^T, masked softmax over keys in registers, P -> LDS,
 // O = P v, out-projection accumulated in registers across heads.  Then residual, LN2, MLP, residual.
 // ==========================================================================================
-#define STAMP(i) do { if (stamp_on) { a.stamps[(i)] = __builtin_readcyclecounter(); } } while (0)
-
 template <class P>
 struct FwdSmem {
     typedef typename P::elem elem;

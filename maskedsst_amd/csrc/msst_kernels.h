@@ -87,6 +87,8 @@ struct AttnBwdArgs {
     int ntiles, H;
     long ntok;
     float scale;
+    int dbg;
+    unsigned long long* stamps;
 };
 
 struct Ln1BwdArgs {
