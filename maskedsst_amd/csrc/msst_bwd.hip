@@ -189,8 +189,8 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pre = hp[nt][r] + a.w.b1[n0 + r];
-                hv[r] = gelu_erf(pre);
-                dv[r] = dh[nt][r] * gelu_erf_grad(pre);
+                hv[r] = P::gelu(pre);
+                dv[r] = dh[nt][r] * P::gelu_grad(pre);
             }
             P::st_nat(&sm.h[wave * 16][nt * 16], LDH, hv);
             P::st_nat(&sm.dhp[wave * 16][nt * 16], LDH, dv);

@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = nt * 16 + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_erf(hh[nt][r] + a.w.b1[n0 + r]);
+            for (int r = 0; r < 4; ++r) hh[nt][r] = P::gelu(hh[nt][r] + a.w.b1[n0 + r]);
             P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);  // h[row][n]
         }
         __builtin_amdgcn_wave_barrier();
@@ -373,6 +373,15 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
         lnp[288 + tid] = a.w.ln2_g[tid]; lnp[384 + tid] = a.w.ln2_b[tid]; lnp[480 + tid] = a.w.b2[tid];
         if (tid < 64) lnp[576 + tid] = a.w.b1[tid];
     }
+    // MLP weights (tile invariant, 24 fragment-packed KB) stay in LDS for the life of the workgroup
+    char* wmlp = smem_raw + sizeof(SM) + 640 * sizeof(float);   // [w1: 12 frags | w2: 12 frags]
+#pragma unroll
+    for (int i6 = 0; i6 < 6; ++i6) {
+        const int f = wave * 6 + i6;
+        dma_frag(f < 12 ? reinterpret_cast<const char*>(w1) + f * 1024 : reinterpret_cast<const char*>(w2) + (f - 12) * 1024,
+                 wmlp + f * 1024);
+    }
+    wait_vm0();
     __syncthreads();
 
     // rows of the first tile
@@ -536,12 +545,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
         STAMP(3 + H * 8);
 
         // ---------------- epilogue: residual, LN2, MLP, residual ----------------
-        frag w1f[4][3];
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks)
-                w1f[nt][ks] = P::ld_w(w1, 96, nt * 16, ks * 32);
+        STAMP(80);
         float x1[6][4];
         float s1 = 0.f;
 #pragma unroll
@@ -556,6 +560,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
             }
             if (a.x1 && tok >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
         }
+        STAMP(81);
         s1 = colgroup_sum(s1);
         const float mean = s1 * (1.f / 96.f);
         float vs = 0.f;
@@ -573,12 +578,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
             for (int r = 0; r < 4; ++r) n4[r] = (x1[mt][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
             P::st_nat(&sm.xn[wave * 16][mt * 16], LDX, n4);
         }
-        frag w2f[6][2];
-#pragma unroll
-        for (int mt = 0; mt < 6; ++mt)
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                w2f[mt][ks] = P::ld_w(w2, 64, mt * 16, ks * 32);
+        STAMP(82);
         __builtin_amdgcn_wave_barrier();
         f32x4 hh[4];
 #pragma unroll
@@ -587,15 +587,17 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
         for (int ks = 0; ks < 3; ++ks) {
             const frag xb = P::ld_kc(&sm.xn[wave * 16][ks * 32], LDX);
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(w1f[nt][ks], xb, hh[nt]);
+            for (int nt = 0; nt < 4; ++nt) hh[nt] = P::mma(*reinterpret_cast<const frag*>(wmlp + (nt * 3 + ks) * 1024 + l * 16), xb, hh[nt]);
         }
+        STAMP(83);
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = nt * 16 + 4 * g;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_erf(hh[nt][r] + lnp[576 + n0 + r]);
+            for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_fast(hh[nt][r] + lnp[576 + n0 + r]);
             P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);
         }
+        STAMP(84);
         __builtin_amdgcn_wave_barrier();
         f32x4 yy[6];
 #pragma unroll
@@ -604,8 +606,9 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
         for (int ks = 0; ks < 2; ++ks) {
             const frag hb = P::ld_kc(&sm.p[wave * 16][ks * 32], LDH);
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(w2f[mt][ks], hb, yy[mt]);
+            for (int mt = 0; mt < 6; ++mt) yy[mt] = P::mma(*reinterpret_cast<const frag*>(wmlp + (12 + mt * 2 + ks) * 1024 + l * 16), hb, yy[mt]);
         }
+        STAMP(85);
         if (tok >= 0) {
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
@@ -714,7 +717,7 @@ static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
 
 static int launch_block_fwd_bf16(const BlockArgs& a, int grid, hipStream_t st) {
     static bool attr_set = false;
-    const size_t smem = sizeof(FwdSmem<PBF16>) + 640 * sizeof(float);
+    const size_t smem = sizeof(FwdSmem<PBF16>) + 640 * sizeof(float) + 24 * 1024;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_bf16_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);

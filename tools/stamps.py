@@ -22,8 +22,9 @@ names = {0: "tile start", 1: "LN1 done", 2: "barrier"}
 for h in range(H):
     names.update({3 + 8*h: f"h{h} start", 4 + 8*h: f"h{h} A done", 5 + 8*h: f"h{h} barrier", 6 + 8*h: f"h{h} softmax+P st",
                   7 + 8*h: f"h{h} O st", 8 + 8*h: f"h{h} outproj", 9 + 8*h: f"h{h} barrier2"})
-names.update({3 + 8*H: "heads done", 4 + 8*H: "epilogue done", 5 + 8*H: "final barrier"})
+names.update({3 + 8*H: "heads done", 80: "e: w1f issued", 81: "e: x1 + store", 82: "e: LN2 + xn2 st", 83: "e: w2f issue+MLP1", 84: "e: gelu + st", 85: "e: MLP2", 4 + 8*H: "epilogue done", 5 + 8*H: "final barrier"})
 prev = t0
-for i in sorted(names):
+order = sorted(k for k in names if k < 68) + [80,81,82,83,84,85] + [4+8*H, 5+8*H]
+for i in order:
     print(f"{names[i]:18s} +{s[i]-prev:7d}  (t={s[i]-t0})")
     prev = s[i]
