@@ -70,7 +70,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
@@ -89,7 +89,7 @@ def main():
     model = SimMIMSpatialSpectral(encoder=enc, masking_ratio=0.7, mask_patch_size=4, tube_masking=True,
                                   to_pixels_per_spectral_block=True).to(dev)
     opt = FusedAdamW(model, lr=0.008, weight_decay=0.05, grad_clamp=1.0)
-    reducer = attach_data_parallel(model) if world > 1 else None
+    reducer = attach_data_parallel(model) if dist.is_initialized() else None
 
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(SEED + rank)
@@ -175,7 +175,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -15,6 +15,7 @@ remaining backward kernels.  It only needs a flat tensor and a bucket list, so t
 exercise the same code on CPU tensors.
 """
 import ctypes
+import os
 
 import torch
 import torch.distributed as dist
@@ -26,6 +27,8 @@ class BucketReducer:
         self.flat = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # MSST_FORCE_DP=1: issue the collectives even with a single rank (exercises the RCCL path on a 1-GPU box)
+        self.force = dist.is_initialized() and os.environ.get("MSST_FORCE_DP", "0") == "1"
         self.bucket_bytes = bucket_bytes
         self.average_in_optimizer = average_in_optimizer
         self.order = [b[0] for b in buckets]
@@ -39,7 +42,7 @@ class BucketReducer:
 
     def bucket_ready(self, name, start=None, end=None):
         """called (in backward order) when a bucket's gradients are final"""
-        if self.world == 1:
+        if self.world == 1 and not self.force:
             return
         s, e = self.range[name]
         self.done.add(name)
@@ -65,7 +68,7 @@ class BucketReducer:
     def finish(self):
         """flush the tail and wait for every outstanding all-reduce; returns the scale still to be
         applied to the gradients (1/world when the optimizer does the averaging)."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self._flush()
             for h in self.handles:
                 h.wait()
