@@ -58,6 +58,8 @@ def main():
     ap.add_argument("--depth", type=int, default=12)
     ap.add_argument("--heads", type=int, default=8)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dropout", type=float, default=0.1,
+                    help="transformer dropout in training mode (reference configs/config.yaml:23-24 ships 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=4)
@@ -84,10 +86,12 @@ def main():
     S = args.bands // 10
     enc = ViTSpatialSpectral(
         image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=8, dim=96, depth=args.depth,
-        heads=args.heads, mlp_dim=64, dropout=0.0, emb_dropout=0.0, channels=args.bands, spectral_pos_embed=False,
+        heads=args.heads, mlp_dim=64, dropout=args.dropout, emb_dropout=args.dropout, channels=args.bands,
+        spectral_pos_embed=False,
         spectral_pos=torch.arange(S), blockwise_patch_embed=True, spectral_only=False, precision=args.precision)
     model = SimMIMSpatialSpectral(encoder=enc, masking_ratio=0.7, mask_patch_size=4, tube_masking=True,
                                   to_pixels_per_spectral_block=True).to(dev)
+    model.train()
     opt = FusedAdamW(model, lr=0.008, weight_decay=0.05, grad_clamp=1.0)
     reducer = attach_data_parallel(model) if dist.is_initialized() else None
 
@@ -151,7 +155,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"SimMIM pretrain step (fwd+bwd+AdamW), EnMAP-shape cubes 8x8x{args.bands}, "
-                                   f"depth {args.depth}x2, dim 96, heads {args.heads}, mlp 64, mask 0.7/4/tube, dropout 0",
+                                   f"depth {args.depth}x2, dim 96, heads {args.heads}, mlp 64, mask 0.7/4/tube, dropout {args.dropout}",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
             "step_mfma_frac": round(value / world * 3 * fwd_flops / (peak * 1e12), 4),
             "gflop_per_sample_step": round(3 * fwd_flops / 1e9, 3),

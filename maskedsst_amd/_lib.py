@@ -5,7 +5,7 @@ library with ``python -m maskedsst_amd.build`` (hipcc, gfx950).
 """
 import ctypes
 import os
-from ctypes import c_int, c_int32, c_long, c_float, c_void_p, c_char_p, POINTER, Structure
+from ctypes import c_int, c_int32, c_uint32, c_long, c_float, c_void_p, c_char_p, POINTER, Structure
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmsst.so")
@@ -46,13 +46,13 @@ _SIGS = {
     "msst_prep_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
     "msst_tokenize_fwd": (c_int, [_P] * 9 + [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, _P]),
+                               c_int, c_int, c_float, c_uint32, c_int, _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                               c_int, _P]),
     "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
                               c_int, c_int, _P]),
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
-                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
     "msst_debug_stamps": (c_int, [_P]),
     "msst_profile_enable": (c_int, [c_int]),

@@ -90,6 +90,18 @@ static TileMap make_tilemap(int mode, int B, int S, int N) {
     return tm;
 }
 
+static Drop make_drop(float p, uint32_t seed, int layer) {
+    Drop d;
+    d.seed = seed; d.layer = layer;
+    if (p > 0.f) {
+        d.thr = (unsigned)(p * 65536.0f + 0.5f);
+        d.scale = 1.0f / (1.0f - (float)d.thr / 65536.0f);   // exact inverse of the realised keep probability
+    } else {
+        d.thr = 0; d.scale = 1.0f;
+    }
+    return d;
+}
+
 static int ntiles_of(const TileMap& tm) { return (tm.nseq + tm.TS - 1) / tm.TS; }
 
 static BlockWeights to_bw(const MsstBlockWeights* w) {
@@ -165,7 +177,8 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
 }
 
 int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x1, int mode, int B, int S,
-                   int N, int heads, int prec, int max_grid, void* stream) {
+                   int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed, int layer,
+                   void* stream) {
     if (!w || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (sequence length > 64)");
     BlockArgs a;
@@ -179,6 +192,7 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     { const char* e = getenv("MSST_DBG"); a.dbg = e ? atoi(e) : 0; }
     a.stamps = g_stamps;
     if (!g_stamps) a.dbg &= ~8;
+    a.drop = make_drop(dropout_p, seed, layer);
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 
@@ -218,12 +232,14 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
 
 int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
                    const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
-                   int nchunk, int mode, int B, int S, int N, int heads, int prec, void* stream) {
+                   int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
+                   uint32_t seed, int layer, void* stream) {
     if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
     hipStream_t st = (hipStream_t)stream;
     const long ntok = (long)B * S * N;
     const BlockWeights bw = to_bw(w);
+    const Drop drop = make_drop(dropout_p, seed, layer);
     const int ntiles_rows = (int)((ntok + 63) / 64);
     const int grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;
     float* slab_mlp = slab;
@@ -236,14 +252,14 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     // 1. MLP half: dy -> dx1
     {
         MlpBwdArgs a;
-        a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok;
+        a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok; a.drop = drop;
         int rc = launch_block_bwd_mlp(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
     }
     // 2. attention half, per (chunk, head)
     {
         aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
-        aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f;
+        aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
         { const char* e = getenv("MSST_DBG"); aa.dbg = e ? atoi(e) : 0; }
         aa.stamps = g_stamps;
         if (!g_stamps) aa.dbg &= ~8;
@@ -253,7 +269,7 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     // 3. LN1 backward + residual
     {
         Ln1BwdArgs a;
-        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = heads;
+        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = heads; a.drop = drop;
         int rc = launch_block_bwd_ln1(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(ln1)");
     }

@@ -145,6 +145,8 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { xhat[mt][r] = xr[r]; dyv[mt][r] = dr[r]; s1 += xr[r]; }
+            // site 4 (MLP-out dropout): the FeedForward branch sees the masked gradient, the residual the raw one
+            if (a.drop.thr && valid) dr = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), dr);
             P::st_nat(&sm.dy[wave * 16][mt * 16], LDX, dr);
         }
         s1 = colgroup_sum(s1);
@@ -186,12 +188,15 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int nt = 0; nt < 4; ++nt) {
             const int n0 = nt * 16 + 4 * g;
             f32x4 hv, dv;
+            f32x4 dhm = dh[nt];
+            if (a.drop.thr && valid) dhm = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), dhm);   // site 3 backward
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pre = hp[nt][r] + a.w.b1[n0 + r];
                 hv[r] = P::gelu(pre);
-                dv[r] = dh[nt][r] * P::gelu_grad(pre);
+                dv[r] = dhm[r] * P::gelu_grad(pre);
             }
+            if (a.drop.thr && valid) hv = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hv);        // site 3 forward
             P::st_nat(&sm.h[wave * 16][nt * 16], LDH, hv);
             P::st_nat(&sm.dhp[wave * 16][nt * 16], LDH, dv);
         }
@@ -526,6 +531,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 f32x4 t4 = zero4();
                 if constexpr (PF) t4 = dav[i];
                 else if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
+                if (a.drop.thr && tok >= 0) t4 = drop4(a.drop, 2, (unsigned)(tok * 24 + pt * 6 + i), t4);   // site 2 backward
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sm.xd[r][pt * 24 + 4 * i + e] = P::cvt(t4[e]);
             }
@@ -569,7 +575,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 pr[t] = pr[t] * inv;
-                P::st_nat(&sm.p[wave * 16][t * 16], LDH, pr[t]);  // p[query][key]
+                f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
+                if (a.drop.thr) pd = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pd);
+                P::st_nat(&sm.p[wave * 16][t * 16], LDH, pd);  // p[query][key]
             }
         }
         STAMP(5);
@@ -619,6 +627,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 const frag db = P::ld_kc(&sm.dO[wave * 16][k0], LDH);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dp[t] = P::mma(P::ld_ks(&sm.vt[k0][t * 16], LDH), db, dp[t]);
+            }
+            if (a.drop.thr) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    dp[t] = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), dp[t]);
             }
             float delta = 0.f;
 #pragma unroll
@@ -836,10 +849,12 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 f32x4 t4 = d1[i], o4;
+                f32x4 tm4 = t4;
+                if (a.drop.thr) tm4 = drop4(a.drop, 2, (unsigned)(tok * 24 + part * 6 + i), tm4);   // site 2 backward
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o4[e] = t4[e] + rstd * (dn[4*i+e] - g1 - v[4*i+e] * g2);
-                    dbo[4*i+e] += t4[e];   // to_out bias grad = column sum of d(attention output) = dx1
+                    dbo[4*i+e] += tm4[e];   // to_out bias grad = column sum of d(attention output before dropout)
                 }
                 dst[i] = o4;
             }

@@ -195,6 +195,34 @@ __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" :
 
 #define STAMP(i) do { if (stamp_on) { a.stamps[(i)] = __builtin_readcyclecounter(); } } while (0)
 
+// ------------------------------------------------------------------------------------------
+// Dropout (reference sites vit_spatial_spectral.py:38,40,57,62).  Counter-based, stateless: the keep
+// mask of 4 consecutive elements is a pure function of (seed, site key, element-group index), so the
+// backward regenerates the forward's mask from the same indices and nothing is stored.
+// keep <=> 16 random bits >= thr, thr = round(p * 65536); kept values are scaled by 1 / (1 - p).
+// (tests/dropout.py holds the bit-identical numpy restatement used to feed the oracle the same masks.)
+// ------------------------------------------------------------------------------------------
+struct Drop {
+    unsigned seed, thr;   // thr == 0: dropout off
+    float scale;
+    int layer;            // block index (0 .. 2*depth-1)
+};
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+// site: 1 = attention probabilities, 2 = to_out, 3 = MLP hidden, 4 = MLP out
+__device__ __forceinline__ f32x4 drop4(const Drop& d, int site, unsigned group, f32x4 v) {
+    const unsigned a = mix32((d.seed ^ ((unsigned)(d.layer * 4 + site) * 0x9E3779B9U)) ^ mix32(group));
+    const unsigned b = mix32(a + 0x85ebca6bU);
+    f32x4 r;
+    r[0] = (a & 0xffffU) >= d.thr ? v[0] * d.scale : 0.f;
+    r[1] = (a >> 16) >= d.thr ? v[1] * d.scale : 0.f;
+    r[2] = (b & 0xffffU) >= d.thr ? v[2] * d.scale : 0.f;
+    r[3] = (b >> 16) >= d.thr ? v[3] * d.scale : 0.f;
+    return r;
+}
+
 // erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7), ~15 VALU ops with v_rcp / v_exp instead of the
 // ~250-cycle libm erff; used by the bf16 kernels (the fp32 parity kernels keep erff)
 __device__ __forceinline__ float erf_fast(float x) {

@@ -223,7 +223,12 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 sum = colgroup_sum(sum);
                 const float inv = 1.f / sum;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) P::st_nat(&sm.p[wave * 16][t * 16], LDH, s[t] * inv);  // p[query][key]
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 pv = s[t] * inv;
+                    if (a.drop.thr)   // site 1: group = ((tile*H + h)*64 + query row)*16 + key/4
+                        pv = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pv);
+                    P::st_nat(&sm.p[wave * 16][t * 16], LDH, pv);  // p[query][key]
+                }
                 STAMP(6 + h * 8);
                 __builtin_amdgcn_wave_barrier();
                 f32x4 o[4];
@@ -264,9 +269,13 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
             const int m0 = mt * 16 + 4 * g;
             f32x4 xr = zero4();
             if (tok >= 0) xr = *reinterpret_cast<const f32x4*>(a.x + tok * 96 + m0);
+            f32x4 av;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) av[r] = oacc[mt][r] + a.w.bo[m0 + r];
+            if (a.drop.thr && tok >= 0) av = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), av);   // site 2
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                x1[mt][r] = oacc[mt][r] + a.w.bo[m0 + r] + xr[r];
+                x1[mt][r] = av[r] + xr[r];
                 s1 += x1[mt][r];
             }
             if (a.x1 && tok >= 0) {
@@ -306,6 +315,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
             const int n0 = nt * 16 + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hh[nt][r] = P::gelu(hh[nt][r] + a.w.b1[n0 + r]);
+            if (a.drop.thr && tok >= 0) hh[nt] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[nt]);   // site 3
             P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);  // h[row][n]
         }
         __builtin_amdgcn_wave_barrier();
@@ -324,7 +334,10 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
                 const int m0 = mt * 16 + 4 * g;
                 f32x4 o4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + a.w.b2[m0 + r] + x1[mt][r];
+                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + a.w.b2[m0 + r];
+                if (a.drop.thr) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);   // site 4
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] += x1[mt][r];
                 *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
             }
         }
@@ -515,7 +528,12 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
                 sum = colgroup_sum(sum);
                 const float inv = 1.f / sum;
 #pragma unroll
-                for (int t = 0; t < 4; ++t) P::st_nat(&sm.p[wave * 16][t * 16], LDH, s[t] * inv);
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 pv = s[t] * inv;
+                    if (a.drop.thr)
+                        pv = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pv);
+                    P::st_nat(&sm.p[wave * 16][t * 16], LDH, pv);
+                }
                 STAMP(6 + h * 8);
                 __builtin_amdgcn_wave_barrier();
                 f32x4 o[4];
@@ -553,8 +571,11 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
             const int m0 = mt * 16 + 4 * g;
             f32x4 o4;
 #pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = oacc[mt][r] + lnp[192 + m0 + r];
+            if (a.drop.thr && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                x1[mt][r] = oacc[mt][r] + lnp[192 + m0 + r] + xres[mt][r];
+                x1[mt][r] = o4[r] + xres[mt][r];
                 o4[r] = x1[mt][r];
                 s1 += x1[mt][r];
             }
@@ -595,6 +616,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
             const int n0 = nt * 16 + 4 * g;
 #pragma unroll
             for (int r = 0; r < 4; ++r) hh[nt][r] = gelu_fast(hh[nt][r] + lnp[576 + n0 + r]);
+            if (a.drop.thr && tok >= 0) hh[nt] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[nt]);
             P::st_nat(&sm.p[wave * 16][nt * 16], LDH, hh[nt]);
         }
         STAMP(84);
@@ -615,7 +637,10 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
                 const int m0 = mt * 16 + 4 * g;
                 f32x4 o4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + lnp[480 + m0 + r] + x1[mt][r];
+                for (int r = 0; r < 4; ++r) o4[r] = yy[mt][r] + lnp[480 + m0 + r];
+                if (a.drop.thr) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] += x1[mt][r];
                 *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
             }
         }

@@ -36,6 +36,7 @@ struct BlockArgs {
     float scale;      // dim_head^-0.5
     int dbg;          // ablation switches for kernel studies (0 in production)
     unsigned long long* stamps;  // dbg & 8: s_memtime stamps of one wave (kernel studies)
+    Drop drop;
 };
 
 struct TokArgs {
@@ -78,6 +79,7 @@ struct MlpBwdArgs {
     BlockWeights w;
     const float* x1; const float* dy; float* dx1; float* slab;
     long ntok;
+    Drop drop;
 };
 
 struct AttnBwdArgs {
@@ -89,12 +91,14 @@ struct AttnBwdArgs {
     float scale;
     int dbg;
     unsigned long long* stamps;
+    Drop drop;
 };
 
 struct Ln1BwdArgs {
     const float* x; const float* dx1; const void* dxn_part; const float* ln1_g; float* dx; float* slab;
     long ntok;
     int H;
+    Drop drop;
 };
 
 struct TokBwdArgs {

@@ -170,7 +170,7 @@ class Engine:
             B, S, N, P, _stream()), "msst_tokenize_fwd")
         return out
 
-    def blocks_fwd(self, x0, save=True):
+    def blocks_fwd(self, x0, save=True, drop=(0.0, 0)):
         """run the 2*depth fused blocks; returns (list of activations [x0 .. x_2L], list of x1)"""
         B = x0.shape[0]
         S, N, H = self.S, self.N, self.enc.heads
@@ -182,7 +182,8 @@ class Engine:
             x1 = torch.empty_like(x) if save else None
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
             _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec, self.max_grid, _stream()), "msst_block_fwd")
+                                               self.prec, self.max_grid, drop[0], drop[1], i, _stream()),
+                       "msst_block_fwd")
             acts.append(y)
             x1s.append(x1)
             x = y
@@ -231,7 +232,7 @@ class Engine:
         self._fire("head")
         return dy
 
-    def blocks_bwd(self, acts, x1s, dy):
+    def blocks_bwd(self, acts, x1s, dy, drop=(0.0, 0)):
         """backward through the 2*depth blocks (reverse order); returns dx0"""
         B = dy.shape[0]
         S, N, H = self.S, self.N, self.enc.heads
@@ -251,7 +252,7 @@ class Engine:
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec,
-                _stream()), "msst_block_bwd")
+                drop[0], drop[1], i, _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g
@@ -286,6 +287,18 @@ class Engine:
         groups, _ = self.fp._ordered()
         return [(n, p) for _, g in groups for n, p in g]
 
+    def dropout_state(self):
+        """(p, seed) for this forward: p = transformer dropout when the encoder is in training mode (the
+        reference's nn.Dropout sites, vit_spatial_spectral.py:38,40,57,62), else 0.  A fresh 32-bit seed is
+        drawn from the torch CPU generator per forward (reproducible under torch.manual_seed); the masks are a
+        stateless function of (seed, layer, site, element) that the backward regenerates."""
+        p = float(self.enc.dropout_p) if self.enc.training else 0.0
+        if p <= 0.0:
+            return 0.0, 0
+        if not 0.0 < p < 1.0:
+            raise ValueError(f"dropout probability {p} outside (0, 1)")
+        return p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+
     def simmim_loss(self, img, bool_mask, idx):
         """scalar loss attached to autograd (reference SimMIMSpatialSpectral.forward :203-340)"""
         self._require_cuda(img)
@@ -306,10 +319,10 @@ class Engine:
         if not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
             self.prep_weights()
             x0 = self.tokenize(img, mask_u8)
-            acts, _ = self.blocks_fwd(x0, save=False)
+            acts, _ = self.blocks_fwd(x0, save=False, drop=self.dropout_state())
             loss, _, _ = self.head_fwd(acts[-1], img, idx32)
             return loss
-        return _SimMIMLossFn.apply(self, names, img, mask_u8, idx32, csr_ptr, csr_pos, *params)
+        return _SimMIMLossFn.apply(self, names, self.dropout_state(), img, mask_u8, idx32, csr_ptr, csr_pos, *params)
 
     # ------------------------------------------------------------------ encoder-level API (inference)
     def transformer(self, tokens):
@@ -339,7 +352,7 @@ class Engine:
                                   "and is not built yet")
 
     # ------------------------------------------------------------------ staged forward (tests / debugging)
-    def simmim_forward_stages(self, img, bool_mask, idx):
+    def simmim_forward_stages(self, img, bool_mask, idx, drop=(0.0, 0)):
         """Forward only, returning the intermediates the golden fixtures pin."""
         self._require_cuda(img)
         self.prep_weights()
@@ -349,7 +362,7 @@ class Engine:
         idx32 = idx.to(device=dev, dtype=torch.int32).contiguous()
         tok_embed = self.tokenize(img, None, with_pos=False)
         x0 = self.tokenize(img, mask_u8)
-        acts, x1s = self.blocks_fwd(x0)
+        acts, x1s = self.blocks_fwd(x0, drop=drop)
         loss, dpred, pred = self.head_fwd(acts[-1], img, idx32, want_pred=True)
         L = self.enc.depth
         return dict(loss=loss, tok_embed=tok_embed, tok_masked=x0, after_spatial=acts[L], enc_out=acts[-1],
@@ -361,10 +374,11 @@ class _SimMIMLossFn(torch.autograd.Function):
     handed to autograd as views of the flat gradient buffer."""
 
     @staticmethod
-    def forward(ctx, eng, names, img, mask_u8, idx32, csr_ptr, csr_pos, *params):
+    def forward(ctx, eng, names, drop, img, mask_u8, idx32, csr_ptr, csr_pos, *params):
         eng.prep_weights()
         x0 = eng.tokenize(img, mask_u8)
-        acts, x1s = eng.blocks_fwd(x0, save=True)
+        acts, x1s = eng.blocks_fwd(x0, save=True, drop=drop)
+        ctx.drop = drop
         loss, dpred, _ = eng.head_fwd(acts[-1], img, idx32)
         ctx.eng = eng
         ctx.names = names
@@ -385,7 +399,7 @@ class _SimMIMLossFn(torch.autograd.Function):
                     "in-place gradient accumulation across backward calls is not supported")
         gout = gout.contiguous().float()
         dy = eng.head_bwd(acts[-1], dpred, csr_ptr, csr_pos, gout)
-        dx0 = eng.blocks_bwd(acts, x1s, dy)
+        dx0 = eng.blocks_bwd(acts, x1s, dy, drop=ctx.drop)
         eng.tokenize_bwd(img, mask_u8, dx0)
         grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
-        return (None,) * 7 + grads
+        return (None,) * 8 + grads

@@ -200,9 +200,11 @@ def encoder_embed(params, img, cfg):
     return patches.reshape(img.shape[0], cfg.T, cfg.P), e
 
 
-def attention(x, wqkv, wo, bo, heads):
+def attention(x, wqkv, wo, bo, heads, drop=None):
     """Attention.forward (vit_spatial_spectral.py:67-78): bias-free qkv, chunk q|k|v, head-major
-    (h d) split, softmax(q k^T * dim_head^-0.5) v, merge, out projection."""
+    (h d) split, softmax(q k^T * dim_head^-0.5) v, merge, out projection.
+    drop: optional dict of pre-scaled keep masks {1: [Bq,h,n,n], 2: [Bq,n,D]} standing in for the two
+    nn.Dropout sites (:73-74 attention probabilities, :62 after to_out)."""
     Bq, n, _ = x.shape
     qkv = x @ wqkv.t()
     inner = wqkv.shape[0] // 3
@@ -213,8 +215,13 @@ def attention(x, wqkv, wo, bo, heads):
     v = v.reshape(Bq, n, heads, dh).transpose(1, 2)
     dots = (q @ k.transpose(-1, -2)) * (dh ** -0.5)
     attn = torch.softmax(dots, dim=-1)
+    if drop is not None:
+        attn = attn * drop[1]
     out = (attn @ v).transpose(1, 2).reshape(Bq, n, inner)
-    return out @ wo.t() + bo
+    out = out @ wo.t() + bo
+    if drop is not None:
+        out = out * drop[2]
+    return out
 
 
 def gelu_erf(x):
@@ -222,35 +229,44 @@ def gelu_erf(x):
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
-def block(x, params, pre, heads):
-    """One Transformer layer: x = attn(LN(x)) + x; x = ff(LN(x)) + x (vit_spatial_spectral.py:100-104)."""
+def block(x, params, pre, heads, drop=None):
+    """One Transformer layer: x = attn(LN(x)) + x; x = ff(LN(x)) + x (vit_spatial_spectral.py:100-104).
+    drop (optional): pre-scaled keep masks for the four dropout sites (1, 2 in Attention; 3 after GELU :38;
+    4 after the second Linear :40)."""
     h = layer_norm(x, params[pre + "0.norm.weight"], params[pre + "0.norm.bias"])
     x = attention(h, params[pre + "0.fn.to_qkv.weight"], params[pre + "0.fn.to_out.0.weight"],
-                  params[pre + "0.fn.to_out.0.bias"], heads) + x
+                  params[pre + "0.fn.to_out.0.bias"], heads, drop) + x
     h = layer_norm(x, params[pre + "1.norm.weight"], params[pre + "1.norm.bias"])
     h = gelu_erf(h @ params[pre + "1.fn.net.0.weight"].t() + params[pre + "1.fn.net.0.bias"])
-    x = h @ params[pre + "1.fn.net.3.weight"].t() + params[pre + "1.fn.net.3.bias"] + x
-    return x
+    if drop is not None:
+        h = h * drop[3]
+    o = h @ params[pre + "1.fn.net.3.weight"].t() + params[pre + "1.fn.net.3.bias"]
+    if drop is not None:
+        o = o * drop[4]
+    return o + x
 
 
-def transformer_forward(params, tokens, cfg, return_mid=False):
+def transformer_forward(params, tokens, cfg, return_mid=False, drop_fn=None):
     """ViTSpatialSpectral.transformer_forward (vit_spatial_spectral.py:410-431,495-499):
     'b (c h w) d -> (b c)(h w) d' -> spatial stack -> '(b c)(h w) d -> (b h w) c d' -> spectral
     stack -> back to 'b (c h w) d'.  No final norm."""
     B = tokens.shape[0]
     S, N, D = cfg.S, cfg.N, cfg.dim
     x = tokens.reshape(B * S, N, D)
+    # drop_fn(layer_index, mode, batch) -> dict of masks for that block (tests feed the kernels' own masks)
     for l in range(cfg.depth):
-        x = block(x, params, f"encoder.spatial_spectral_transformer.1.layers.{l}.", cfg.heads)
+        x = block(x, params, f"encoder.spatial_spectral_transformer.1.layers.{l}.", cfg.heads,
+                  drop_fn(l, 0, B) if drop_fn else None)
     mid = x.reshape(B, cfg.T, D)
     x = x.reshape(B, S, N, D).transpose(1, 2).reshape(B * N, S, D)
     for l in range(cfg.depth):
-        x = block(x, params, f"encoder.spatial_spectral_transformer.3.layers.{l}.", cfg.heads)
+        x = block(x, params, f"encoder.spatial_spectral_transformer.3.layers.{l}.", cfg.heads,
+                  drop_fn(cfg.depth + l, 1, B) if drop_fn else None)
     x = x.reshape(B, N, S, D).transpose(1, 2).reshape(B, cfg.T, D)
     return (x, mid) if return_mid else x
 
 
-def simmim_forward(params, img, cfg, masks=None):
+def simmim_forward(params, img, cfg, masks=None, drop_fn=None):
     """SimMIMSpatialSpectral.forward (vit_simmim_original.py:203-340).  ``masks`` =
     (bool [B,T], int64 [B,K]) or None to draw them like the reference does (numpy global RNG /
     torch CPU RNG).  Returns a dict with the loss and the intermediates the golden fixtures pin."""
@@ -265,7 +281,7 @@ def simmim_forward(params, img, cfg, masks=None):
                            cfg.spatial_patch)
     bool_mask, idx = masks
     tok_masked = torch.where(bool_mask[..., None], mask_tokens, tokens)     # :285
-    enc_out, mid = transformer_forward(params, tok_masked, cfg, return_mid=True)  # :298
+    enc_out, mid = transformer_forward(params, tok_masked, cfg, return_mid=True, drop_fn=drop_fn)  # :298
     br = torch.arange(B)[:, None]
     enc_m = enc_out[br, idx]                                                # :314
     if cfg.to_pixels_per_spectral_block:                                    # :317-330 + :21-40

@@ -11,7 +11,7 @@ Differences from the reference script, all opt-in or forced by the environment:
   * ``--dp``: one process per GPU under ``python -m torch.distributed.run`` (RCCL gradient all-reduce);
   * optimizer: fused AdamW over the flat parameter buffer (``--torch-optim`` keeps torch.optim.AdamW
     with the reference's clamp hooks);
-  * dropout: the fused kernels implement p = 0 only; ``--dropout`` other than 0 is rejected.
+  * dropout: the four transformer dropout sites are fused into the kernels (stateless counter-based masks).
 """
 import argparse
 import os
@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--depth", type=int, default=None)
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--dropout", type=float, default=0.0)
+    ap.add_argument("--dropout", type=float, default=None, help="override transformer_dropout of the config")
     ap.add_argument("--torch-optim", action="store_true")
     ap.add_argument("--save-dir", default=None)
     args = ap.parse_args()
@@ -63,8 +63,8 @@ def main():
         config.batch_size = args.batch_size
     if args.epochs is not None:
         config.epoch = args.epochs
-    if args.dropout != 0.0:
-        raise SystemExit("dropout > 0 is not implemented in the fused kernels yet")
+    if args.dropout is not None:
+        config.transformer_dropout = config.transformer_emb_dropout = args.dropout
     assert config.encoder_name == "ViTSpatialSpectral", f"encoder {config.encoder_name} not available"
 
     spectral_pos = torch.arange(config.n_bands // config.band_patch_size)
@@ -72,7 +72,8 @@ def main():
         image_size=config.image_size, spatial_patch_size=config.patch_size,
         spectral_patch_size=config.band_patch_size, num_classes=config.n_classes,
         dim=config.transformer_dim, depth=config.transformer_depth, heads=config.transformer_n_heads,
-        mlp_dim=config.transformer_mlp_dim, dropout=0.0, emb_dropout=0.0, channels=config.n_bands,
+        mlp_dim=config.transformer_mlp_dim, dropout=config.transformer_dropout,
+        emb_dropout=config.transformer_emb_dropout, channels=config.n_bands,
         spectral_pos_embed=config.spectral_pos_embed, spectral_pos=spectral_pos,
         blockwise_patch_embed=config.blockwise_patch_embed, spectral_only=config.spectral_only,
         precision=args.precision)

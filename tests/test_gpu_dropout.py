@@ -1,0 +1,87 @@
+"""GPU: training-mode dropout (reference sites vit_spatial_spectral.py:38,40,57,62).  The kernels' masks are a
+stateless function of (seed, layer, site, element); tests/dropout.py restates it in numpy so the oracle can
+be run with EXACTLY the same masks -> forward and every gradient are compared tightly in fp32 mode."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import oracle_cfg_from
+from util import build_product, relerr
+from dropout import make_drop_fn
+
+pytestmark = pytest.mark.gpu
+
+CASES = [dict(bands=50, depth=2, B=3), dict(bands=200, depth=1, B=2), dict(bands=30, depth=1, B=2, heads=2)]
+
+
+@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_dropout_fwd_bwd_fp32_same_masks(cfg):
+    from oracle import simmim_forward
+    from maskedsst_amd.masking import inverse_csr
+    p, seed = 0.1, 123457
+    model, params, x = build_product(cfg, precision="fp32", device="cuda")
+    ocfg = oracle_cfg_from(cfg)
+    masks = model.draw_masks(cfg["B"])
+    for q in params.values():
+        q.requires_grad_(True)
+    ref = simmim_forward(params, x, ocfg, masks=masks, drop_fn=make_drop_fn(p, seed, ocfg.S, ocfg.N, ocfg.heads))
+    ref["tok_masked"].retain_grad()
+    ref["loss"].backward()
+    eng = model.engine()
+    xc = x.cuda()
+    out = eng.simmim_forward_stages(xc, masks[0], masks[1], drop=(p, seed))
+    torch.cuda.synchronize()
+    assert relerr(out["enc_out"], ref["enc_out"]) < 1e-4
+    assert abs(out["loss"].item() - ref["loss"].item()) <= 1e-4 * abs(ref["loss"].item())
+    # a run without dropout must differ (the masks really are applied)
+    out0 = eng.simmim_forward_stages(xc, masks[0], masks[1])
+    assert relerr(out0["enc_out"], ref["enc_out"]) > 1e-2
+    ptr, pos = inverse_csr(masks[1].numpy(), eng.S * eng.N)
+    dy = eng.head_bwd(out["enc_out"], out["dpred"], torch.from_numpy(ptr).cuda(), torch.from_numpy(pos).cuda())
+    dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy, drop=(p, seed))
+    eng.tokenize_bwd(xc, masks[0].to(torch.uint8).cuda(), dx0)
+    torch.cuda.synchronize()
+    assert relerr(dx0, ref["tok_masked"].grad) < 2e-4
+    flat = {id(q): n for n, q in eng.trainable()}
+    bad = []
+    for name, q in model.named_parameters():
+        g_ref = params[name].grad
+        if g_ref is None:
+            continue
+        e = relerr(eng.fp.view(flat[id(q)], eng.fp.grad), g_ref)
+        if not e < 2e-4:
+            bad.append((name, e))
+    assert not bad, bad
+
+
+def test_dropout_training_mode_end_to_end_bf16():
+    """model.train() with dropout=0.1: finite loss/grads, different masks per forward, eval() is deterministic"""
+    from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
+    torch.manual_seed(5); np.random.seed(5)
+    enc = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=8, dim=96, depth=2,
+                             heads=8, mlp_dim=64, channels=50, spectral_pos_embed=False, spectral_pos=list(range(5)),
+                             dropout=0.1, emb_dropout=0.1, precision="bf16")
+    model = SimMIMSpatialSpectral(encoder=enc, masking_ratio=0.7, mask_patch_size=4, tube_masking=True,
+                                  to_pixels_per_spectral_block=True).cuda()
+    x = torch.randn(4, 50, 8, 8).cuda()
+    masks = model.draw_masks(4)
+    model.train()
+    l1 = model(x, masks=masks); l1.backward()
+    g1 = model.mask_token.grad.clone()
+    model.zero_grad(set_to_none=True)
+    l2 = model(x, masks=masks); l2.backward()
+    assert torch.isfinite(l1) and torch.isfinite(l2) and torch.isfinite(g1).all()
+    assert l1.item() != l2.item()          # fresh seed per forward
+    model.eval()
+    with torch.no_grad():
+        e1, e2 = model(x, masks=masks), model(x, masks=masks)
+    assert e1.item() == e2.item()
+
+
+def test_mask_statistics():
+    from dropout import keep_scaled
+    g = np.arange(200000)
+    k = np.stack([keep_scaled(0.1, 99, 3, 2, g, np.full_like(g, e)) for e in range(4)])
+    rate = float((k > 0).mean())
+    assert abs(rate - 0.9) < 2e-3
+    assert abs(float(k.mean()) - 1.0) < 3e-3      # unbiased after scaling
