@@ -72,11 +72,12 @@ typedef struct MsstBlockWeights {
  * img [B][S*P][N]; mask [B][T] bytes (all zero for the classification path);
  * pos_split == 0: pos_a = learned table [T][96] (pos_embedding[0,:T]);
  * pos_split  > 0: pos_a = pos_embed [N][pos_split], pos_b = channel_embed [S][96-pos_split]
- *                 (get_pos_embeddings, vit_spatial_spectral.py:501-516).  out [B][T][96]. */
+ *                 (get_pos_embeddings, vit_spatial_spectral.py:501-516).  out [B][T][96].
+ * emb_dropout_p > 0: embedding dropout on (token + pos) (forward_features, :530; classification path). */
 int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,
                       const float* b_emb, const float* post_g, const float* post_b, const float* pos_a,
                       const float* pos_b, int pos_split, const float* mask_token, const uint8_t* mask,
-                      float* out, int B, int S, int N, int P, void* stream);
+                      float* out, int B, int S, int N, int P, float emb_dropout_p, uint32_t seed, void* stream);
 
 /* a7-a10: one fused pre-norm transformer block (PreNorm+Attention+FeedForward+residuals,
  * vit_spatial_spectral.py:22-104) over all B*S*N tokens; mode selects the spatial or spectral
@@ -140,7 +141,16 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
                       const float* dx0, float* slab, int nchunk, float* dpre_g, float* dpre_b,
                       float* dw_emb, float* db_emb, float* dpost_g, float* dpost_b, float* dpos_a,
                       float* dpos_b, int pos_split, float* dmask_token, int B, int S, int N, int P,
-                      void* stream);
+                      float emb_dropout_p, uint32_t seed, void* stream);
+
+/* a17: classification head of ViTSpatialSpectral.forward (vit_spatial_spectral.py:536-564, :481-493):
+ * mean over the spectral axis -> LayerNorm(96) -> Linear(96 -> n_classes); logits [B][n_classes][N].
+ * _bwd: dy [B][T][96] fully written; slab B*(n_classes*97 + 192) floats. */
+int msst_cls_head_fwd(const float* y, const float* ln_g, const float* ln_b, const float* w, const float* b,
+                      float* logits, int B, int S, int N, int n_classes, void* stream);
+int msst_cls_head_bwd(const float* y, const float* dlogits, const float* ln_g, const float* ln_b, const float* w,
+                      float* dy, float* slab, float* dln_g, float* dln_b, float* dw, float* db, int B, int S,
+                      int N, int n_classes, void* stream);
 
 /* Fused AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, src/utils.py:36-45), with the
  * reference's value clamp of the gradient (pretrain.py:71-73) when clamp > 0. */

@@ -44,7 +44,9 @@ _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),
     "msst_prep_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
-    "msst_tokenize_fwd": (c_int, [_P] * 9 + [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "msst_tokenize_fwd": (c_int, [_P] * 9 + [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint32, _P]),
+    "msst_cls_head_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_int, _P]),
+    "msst_cls_head_bwd": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_int, _P]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_uint32, c_int, _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
@@ -53,7 +55,8 @@ _SIGS = {
                               c_int, c_int, _P]),
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
                                c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P]),
-    "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, _P]),
+    "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, c_float,
+                                  c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),
     "msst_profile_enable": (c_int, [c_int]),
     "msst_profile_kernels": (c_int, []),

@@ -168,8 +168,9 @@ int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int max_elems, int pre
 int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,
                       const float* b_emb, const float* post_g, const float* post_b, const float* pos_a,
                       const float* pos_b, int pos_split, const float* mask_token, const uint8_t* mask,
-                      float* out, int B, int S, int N, int P, void* stream) {
+                      float* out, int B, int S, int N, int P, float emb_dropout_p, uint32_t seed, void* stream) {
     TokArgs a;
+    a.drop = make_drop(emb_dropout_p, seed, 255);
     a.img = img; a.pre_g = pre_g; a.pre_b = pre_b; a.w_emb = w_emb; a.b_emb = b_emb;
     a.post_g = post_g; a.post_b = post_b; a.pos_a = pos_a; a.pos_b = pos_b; a.mask_token = mask_token;
     a.mask = mask; a.out = out; a.B = B; a.S = S; a.N = N; a.T = S * N; a.P = P; a.pos_split = pos_split;
@@ -311,10 +312,11 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
                       const float* dx0, float* slab, int nchunk, float* dpre_g, float* dpre_b,
                       float* dw_emb, float* db_emb, float* dpost_g, float* dpost_b, float* dpos_a,
                       float* dpos_b, int pos_split, float* dmask_token, int B, int S, int N, int P,
-                      void* stream) {
+                      float emb_dropout_p, uint32_t seed, void* stream) {
     if (nchunk < 1) return fail(MSST_ERR_BADARG, "msst_tokenize_bwd");
     hipStream_t st = (hipStream_t)stream;
     TokBwdArgs a;
+    a.drop = make_drop(emb_dropout_p, seed, 255);
     a.img = img; a.pre_g = pre_g; a.pre_b = pre_b; a.w_emb = w_emb; a.b_emb = b_emb; a.post_g = post_g;
     a.post_b = post_b; a.mask = mask; a.dx0 = dx0; a.slab = slab; a.B = B; a.S = S; a.N = N; a.T = S * N; a.P = P;
     int rc = launch_tokenize_bwd(a, nchunk, st);
@@ -347,6 +349,33 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
     rc = launch_reduce_segs(rb.r, st);
     if (!rc && pos_split) rc = launch_pos_split(stage, S, N, pos_split, dpos_a, dpos_b, st);
     return fail(rc, "msst_tokenize_bwd(reduce)");
+}
+
+int msst_cls_head_fwd(const float* y, const float* ln_g, const float* ln_b, const float* w, const float* b,
+                      float* logits, int B, int S, int N, int n_classes, void* stream) {
+    ClsArgs a;
+    a.y = y; a.ln_g = ln_g; a.ln_b = ln_b; a.w = w; a.b = b; a.logits = logits;
+    a.B = B; a.S = S; a.N = N; a.T = S * N; a.NC = n_classes;
+    return fail(launch_cls_head_fwd(a, (hipStream_t)stream), "msst_cls_head_fwd");
+}
+
+int msst_cls_head_bwd(const float* y, const float* dlogits, const float* ln_g, const float* ln_b, const float* w,
+                      float* dy, float* slab, float* dln_g, float* dln_b, float* dw, float* db, int B, int S,
+                      int N, int n_classes, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    ClsBwdArgs a;
+    a.y = y; a.dlogits = dlogits; a.ln_g = ln_g; a.ln_b = ln_b; a.w = w; a.dy = dy; a.slab = slab;
+    a.B = B; a.S = S; a.N = N; a.T = S * N; a.NC = n_classes;
+    int rc = launch_cls_head_bwd(a, st);
+    if (rc) return fail(rc, "msst_cls_head_bwd");
+    const long ss = (long)n_classes * 96 + n_classes + 192;
+    RSegBuilder rb;
+    bool ok = rb.add(slab, ss, B, dw, n_classes * 96);
+    ok = ok && rb.add(slab + n_classes * 96, ss, B, db, n_classes);
+    ok = ok && rb.add(slab + n_classes * 96 + n_classes, ss, B, dln_g, 96);
+    ok = ok && rb.add(slab + n_classes * 96 + n_classes + 96, ss, B, dln_b, 96);
+    if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_cls_head_bwd");
+    return fail(launch_reduce_segs(rb.r, st), "msst_cls_head_bwd(reduce)");
 }
 
 int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,

@@ -913,7 +913,11 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             float dt[24];
             const f32x4* dsrc = reinterpret_cast<const f32x4*>(a.dx0 + ((long)b * T + t) * 96 + part * 24);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { f32x4 t4 = dsrc[i]; dt[4*i] = t4[0]; dt[4*i+1] = t4[1]; dt[4*i+2] = t4[2]; dt[4*i+3] = t4[3]; }
+            for (int i = 0; i < 6; ++i) {
+                f32x4 t4 = dsrc[i];
+                if (a.drop.thr) t4 = drop4(a.drop, 0, (unsigned)(((long)b * T + t) * 24 + part * 6 + i), t4);   // emb dropout backward
+                dt[4*i] = t4[0]; dt[4*i+1] = t4[1]; dt[4*i+2] = t4[2]; dt[4*i+3] = t4[3];
+            }
 #pragma unroll
             for (int i = 0; i < 24; ++i) dpos[i] += dt[i];
             // recompute
@@ -1137,6 +1141,110 @@ int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, flo
     const int n = N * split + S * (96 - split);
     ProfScope ps(K_POS_SPLIT, st);
     hipLaunchKernelGGL(pos_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dpos, S, N, split, dpe, dce);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst
+
+namespace msst {
+
+// ==========================================================================================
+// classification head backward (forward: cls_head_fwd_kernel).  grid (B), 256 threads.
+// slab per sample: [dW NC*96 | db NC | dgamma 96 | dbeta 96]; dy [B][T][96] fully written
+// (every spectral block of a position receives d(mean) / S).
+// ==========================================================================================
+__global__ __launch_bounds__(256) void cls_head_bwd_kernel(ClsBwdArgs a) {
+    __shared__ float xn_s[64][97];
+    __shared__ float dl_s[64][33];
+    const int b = blockIdx.x, tid = threadIdx.x, n = tid >> 2, part = tid & 3;
+    const int NC = a.NC;
+    const bool active = n < a.N;
+    float dg[24], db[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    if (active) {
+        float m[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) m[i] = 0.f;
+        for (int c = 0; c < a.S; ++c) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.y + ((long)b * a.T + c * a.N + n) * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) { const f32x4 t4 = src[i]; m[4*i] += t4[0]; m[4*i+1] += t4[1]; m[4*i+2] += t4[2]; m[4*i+3] += t4[3]; }
+        }
+        const float invS = 1.f / a.S;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { m[i] *= invS; s += m[i]; }
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+        const float mean = s * (1.f / 96.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { const float d = m[i] - mean; vs += d * d; }
+        vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+        const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+        float dxn[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { m[i] = (m[i] - mean) * rstd; dxn[i] = 0.f; }   // m = xhat
+        for (int k = 0; k < NC; ++k) {
+            const float dl = a.dlogits[((long)b * NC + k) * a.N + n];
+            if (part == 0) dl_s[n][k] = dl;
+#pragma unroll
+            for (int i = 0; i < 24; ++i) dxn[i] += dl * a.w[k * 96 + part * 24 + i];
+        }
+        float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) {
+            const int d = part * 24 + i;
+            xn_s[n][d] = m[i] * a.ln_g[d] + a.ln_b[d];
+            dg[i] = dxn[i] * m[i];
+            db[i] = dxn[i];
+            dxn[i] *= a.ln_g[d];
+            g1 += dxn[i];
+            g2 += dxn[i] * m[i];
+        }
+        g1 += __shfl_xor(g1, 1); g1 += __shfl_xor(g1, 2);
+        g2 += __shfl_xor(g2, 1); g2 += __shfl_xor(g2, 2);
+        g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
+        f32x4 o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[i][e] = rstd * (dxn[4*i+e] - g1 - m[4*i+e] * g2) * invS;
+        for (int c = 0; c < a.S; ++c) {
+            f32x4* dst = reinterpret_cast<f32x4*>(a.dy + ((long)b * a.T + c * a.N + n) * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) dst[i] = o[i];
+        }
+    }
+    __syncthreads();
+    float* slab = a.slab + (long)b * (NC * 96 + NC + 192);
+    for (int idx = tid; idx < NC * 96; idx += 256) {
+        const int k = idx / 96, d = idx - k * 96;
+        float s = 0.f;
+        for (int nn = 0; nn < a.N; ++nn) s += dl_s[nn][k] * xn_s[nn][d];
+        slab[idx] = s;
+    }
+    if (tid < NC) {
+        float s = 0.f;
+        for (int nn = 0; nn < a.N; ++nn) s += dl_s[nn][tid];
+        slab[NC * 96 + tid] = s;
+    }
+    for (int which = 0; which < 2; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 24; ++i) xn_s[n][part * 24 + i] = active ? (which ? db[i] : dg[i]) : 0.f;
+        __syncthreads();
+        if (tid < 96) {
+            float s = 0.f;
+            for (int nn = 0; nn < 64; ++nn) s += xn_s[nn][tid];
+            slab[NC * 96 + NC + which * 96 + tid] = s;
+        }
+    }
+}
+
+int launch_cls_head_bwd(const ClsBwdArgs& a, hipStream_t st) {
+    if (a.N > 64 || a.NC > 32) return MSST_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cls_head_bwd_kernel, dim3(a.B), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 

@@ -68,7 +68,13 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
         if (a.pos_split) pos = d < a.pos_split ? a.pos_a[n * a.pos_split + d] : a.pos_b[c * (96 - a.pos_split) + d - a.pos_split];
         else pos = a.pos_a[(long)t * 96 + d];
         const float tok = (e[i] - m2) * rstd2 * a.post_g[d] + a.post_b[d];
-        dst[i] = (masked ? a.mask_token[d] : tok) + pos;
+        e[i] = (masked ? a.mask_token[d] : tok) + pos;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        f32x4 v = {e[4*i], e[4*i+1], e[4*i+2], e[4*i+3]};
+        if (a.drop.thr) v = drop4(a.drop, 0, (unsigned)(((long)b * a.T + t) * 24 + part * 6 + i), v);   // emb dropout
+        reinterpret_cast<f32x4*>(dst)[i] = v;
     }
 }
 
@@ -776,6 +782,54 @@ int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {
     const float scale = 1.0f / ((float)a.B * (float)a.K * (float)a.P) / (float)a.K;
     ProfScope ps(K_LOSS_REDUCE, st);
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, st, a.partial, np, scale, loss);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst
+
+namespace msst {
+
+// ==========================================================================================
+// classification head (row a17): reference vit_spatial_spectral.py:536-564 + :481-493 --
+// 'b (c h w) d -> b c h w d', mean over the spectral axis c, LayerNorm(96), Linear(96 -> n_classes),
+// output [B, n_classes, H*W].  grid (B), 256 threads = 4 threads per spatial position, 24 features each.
+// ==========================================================================================
+__global__ __launch_bounds__(256) void cls_head_fwd_kernel(ClsArgs a) {
+    const int b = blockIdx.x, tid = threadIdx.x, n = tid >> 2, part = tid & 3;
+    if (n >= a.N) return;
+    float m[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) m[i] = 0.f;
+    for (int c = 0; c < a.S; ++c) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.y + ((long)b * a.T + c * a.N + n) * 96 + part * 24);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { const f32x4 t4 = src[i]; m[4*i] += t4[0]; m[4*i+1] += t4[1]; m[4*i+2] += t4[2]; m[4*i+3] += t4[3]; }
+    }
+    const float invS = 1.f / a.S;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { m[i] *= invS; s += m[i]; }
+    s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+    const float mean = s * (1.f / 96.f);
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) { const float d = m[i] - mean; vs += d * d; }
+    vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+    const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < 24; ++i) m[i] = (m[i] - mean) * rstd * a.ln_g[part * 24 + i] + a.ln_b[part * 24 + i];
+    for (int k = 0; k < a.NC; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) acc += a.w[k * 96 + part * 24 + i] * m[i];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+        if (part == 0) a.logits[((long)b * a.NC + k) * a.N + n] = acc + a.b[k];
+    }
+}
+
+int launch_cls_head_fwd(const ClsArgs& a, hipStream_t st) {
+    if (a.N > 64) return MSST_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cls_head_fwd_kernel, dim3(a.B), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 

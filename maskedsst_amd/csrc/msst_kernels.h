@@ -51,6 +51,7 @@ struct TokArgs {
     const uint8_t* mask;     // [B][T] (1 = masked); all-zero for the classification path
     float* out;              // [B][T][96]
     int B, S, N, T, P, pos_split;
+    Drop drop;               // embedding dropout on (token + pos) (vit_spatial_spectral.py:530), classification path only
 };
 
 struct HeadArgs {
@@ -105,6 +106,7 @@ struct TokBwdArgs {
     const float* img; const float* pre_g; const float* pre_b; const float* w_emb; const float* b_emb;
     const float* post_g; const float* post_b; const uint8_t* mask; const float* dx0; float* slab;
     int B, S, N, T, P;
+    Drop drop;
 };
 
 // ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
@@ -119,6 +121,18 @@ struct ProfScope {
     ProfScope(int id, hipStream_t s) : st(s) { prof_begin(id, s); }
     ~ProfScope() { prof_end(st); }
 };
+
+struct ClsArgs {
+    const float* y; const float* ln_g; const float* ln_b; const float* w; const float* b; float* logits;
+    int B, S, N, T, NC;
+};
+struct ClsBwdArgs {
+    const float* y; const float* dlogits; const float* ln_g; const float* ln_b; const float* w;
+    float* dy; float* slab;
+    int B, S, N, T, NC;
+};
+int launch_cls_head_fwd(const ClsArgs& a, hipStream_t st);
+int launch_cls_head_bwd(const ClsBwdArgs& a, hipStream_t st);
 
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st);
 int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st);

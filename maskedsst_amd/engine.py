@@ -138,7 +138,7 @@ class Engine:
                    "msst_prep_weights")
 
     # ------------------------------------------------------------------ forward pieces
-    def tokenize(self, img, mask_u8=None, with_pos=True):
+    def tokenize(self, img, mask_u8=None, with_pos=True, emb_drop=(0.0, 0)):
         """img [B, C, H, W] fp32 cuda -> tokens [B, T, 96] (pos added, mask token substituted)"""
         self._require_cuda(img)
         self.ensure()
@@ -167,7 +167,7 @@ class Engine:
         _lib.check(self.lib.msst_tokenize_fwd(
             _p(img), V(fp.ptr("pre_g")), V(fp.ptr("pre_b")), V(fp.ptr("embed.w.0")), V(fp.ptr("embed.b.0")),
             V(fp.ptr("post_g")), V(fp.ptr("post_b")), V(pos_a), V(pos_b), split, V(mt), _p(mask_u8), _p(out),
-            B, S, N, P, _stream()), "msst_tokenize_fwd")
+            B, S, N, P, emb_drop[0], emb_drop[1], _stream()), "msst_tokenize_fwd")
         return out
 
     def blocks_fwd(self, x0, save=True, drop=(0.0, 0)):
@@ -257,7 +257,7 @@ class Engine:
             self._fire(f"{sname}.{l}")
         return g
 
-    def tokenize_bwd(self, img, mask_u8, dx0):
+    def tokenize_bwd(self, img, mask_u8, dx0, emb_drop=(0.0, 0)):
         B = img.shape[0]
         S, N, P = self.S, self.N, self.P
         dev = img.device
@@ -277,8 +277,8 @@ class Engine:
             _p(img), V(fp.ptr("pre_g")), V(fp.ptr("pre_b")), V(fp.ptr("embed.w.0")), V(fp.ptr("embed.b.0")),
             V(fp.ptr("post_g")), V(fp.ptr("post_b")), _p(mask_u8), _p(dx0), _p(slab), nchunk,
             V(fp.ptr("pre_g", g)), V(fp.ptr("pre_b", g)), V(fp.ptr("embed.w.0", g)), V(fp.ptr("embed.b.0", g)),
-            V(fp.ptr("post_g", g)), V(fp.ptr("post_b", g)), V(dpa), V(dpb), split, V(dmt), B, S, N, P, _stream()),
-            "msst_tokenize_bwd")
+            V(fp.ptr("post_g", g)), V(fp.ptr("post_b", g)), V(dpa), V(dpb), split, V(dmt), B, S, N, P,
+            emb_drop[0], emb_drop[1], _stream()), "msst_tokenize_bwd")
         self._fire("tokenizer")
 
     # ------------------------------------------------------------------ autograd entry (SimMIM loss)
@@ -347,9 +347,55 @@ class Engine:
         x0 = self.tokenize(img, None, with_pos=True)
         return self.transformer(x0)
 
+    # ------------------------------------------------------------------ classification (row a17 / finetune.py)
+    def cls_head_fwd(self, y):
+        B = y.shape[0]
+        nc = self.enc.num_classes
+        logits = torch.empty(B, nc, self.N, dtype=torch.float32, device=y.device)
+        fp = self.fp
+        V = ctypes.c_void_p
+        _lib.check(self.lib.msst_cls_head_fwd(
+            _p(y), V(fp.ptr("mlp_head.0.weight")), V(fp.ptr("mlp_head.0.bias")), V(fp.ptr("mlp_head.1.weight")),
+            V(fp.ptr("mlp_head.1.bias")), _p(logits), B, self.S, self.N, nc, _stream()), "msst_cls_head_fwd")
+        return logits
+
+    def cls_head_bwd(self, y, dlogits):
+        B = y.shape[0]
+        nc = self.enc.num_classes
+        dy = torch.empty_like(y)
+        slab = torch.empty(B * (nc * 97 + 192), dtype=torch.float32, device=y.device)
+        fp, g = self.fp, self.fp.grad
+        V = ctypes.c_void_p
+        _lib.check(self.lib.msst_cls_head_bwd(
+            _p(y), _p(dlogits), V(fp.ptr("mlp_head.0.weight")), V(fp.ptr("mlp_head.0.bias")),
+            V(fp.ptr("mlp_head.1.weight")), _p(dy), _p(slab), V(fp.ptr("mlp_head.0.weight", g)),
+            V(fp.ptr("mlp_head.0.bias", g)), V(fp.ptr("mlp_head.1.weight", g)), V(fp.ptr("mlp_head.1.bias", g)),
+            B, self.S, self.N, nc, _stream()), "msst_cls_head_bwd")
+        self._fire("cls_head")
+        return dy
+
     def classify(self, img):
-        raise NotImplementedError("the classification head path (finetune.py) is a 'next' row of the scope table "
-                                  "and is not built yet")
+        """ViTSpatialSpectral.forward: logits [B, num_classes, H, W] (reference :536-564)."""
+        self._require_cuda(img)
+        self.ensure()
+        img = img.contiguous().float()
+        H = W = self.enc.num_spatial_patches_sqrt
+        p = float(self.enc.dropout_p) if self.enc.training else 0.0
+        pe = float(self.enc.emb_dropout_p) if self.enc.training else 0.0
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) if (p > 0 or pe > 0) else 0
+        drop, emb_drop = (p, seed), (pe, seed ^ 0x5bd1e995)
+        params = [q for _, q in self.trainable()]
+        if self.mim is not None or not torch.is_grad_enabled() or not any(q.requires_grad for q in params):
+            if self.mim is not None and torch.is_grad_enabled() and any(q.requires_grad for q in params):
+                raise NotImplementedError("train the classifier through a bare ViTSpatialSpectral (as finetune.py "
+                                          "does), not through an encoder wrapped in SimMIMSpatialSpectral")
+            self.prep_weights()
+            x0 = self.tokenize(img, None, emb_drop=emb_drop)
+            acts, _ = self.blocks_fwd(x0, save=False, drop=drop)
+            return self.cls_head_fwd(acts[-1]).view(img.shape[0], -1, H, W)
+        names = [n for n, _ in self.trainable()]
+        out = _ClassifyFn.apply(self, names, drop, emb_drop, img, *params)
+        return out.view(img.shape[0], -1, H, W)
 
     # ------------------------------------------------------------------ staged forward (tests / debugging)
     def simmim_forward_stages(self, img, bool_mask, idx, drop=(0.0, 0)):
@@ -403,3 +449,35 @@ class _SimMIMLossFn(torch.autograd.Function):
         eng.tokenize_bwd(img, mask_u8, dx0)
         grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
         return (None,) * 8 + grads
+
+
+class _ClassifyFn(torch.autograd.Function):
+    """logits = encoder(img) for the classification path; backward through the same HIP kernels."""
+
+    @staticmethod
+    def forward(ctx, eng, names, drop, emb_drop, img, *params):
+        eng.prep_weights()
+        x0 = eng.tokenize(img, None, emb_drop=emb_drop)
+        acts, x1s = eng.blocks_fwd(x0, save=True, drop=drop)
+        logits = eng.cls_head_fwd(acts[-1])
+        ctx.eng, ctx.names, ctx.drop, ctx.emb_drop = eng, names, drop, emb_drop
+        ctx.stash = (img, acts, x1s)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.eng
+        img, acts, x1s = ctx.stash
+        ctx.stash = None
+        lo, hi = eng.fp.grad.data_ptr(), eng.fp.grad.data_ptr() + 4 * eng.fp.grad.numel()
+        for _, p in eng.trainable():
+            if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+                raise RuntimeError("call optimizer.zero_grad(set_to_none=True) before the next backward "
+                                   "(maskedsst_amd hands autograd views of its flat gradient buffer)")
+        dy = eng.cls_head_bwd(acts[-1], dlogits.contiguous().float())
+        dx0 = eng.blocks_bwd(acts, x1s, dy, drop=ctx.drop)
+        if eng._zero_mask is None or eng._zero_mask.numel() < img.shape[0] * eng.S * eng.N:
+            eng._zero_mask = torch.zeros(img.shape[0] * eng.S * eng.N, dtype=torch.uint8, device=img.device)
+        eng.tokenize_bwd(img, eng._zero_mask, dx0, emb_drop=ctx.emb_drop)
+        grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
+        return (None,) * 5 + grads

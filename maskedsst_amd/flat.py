@@ -9,6 +9,7 @@ flat fp32 buffer (the ``state_dict`` keys / shapes of the reference are untouche
 Layout (= backward completion order, so DP buckets are contiguous slices):
     to_pixels | spectral layers L-1..0 | spatial layers L-1..0 | tokenizer (embed, norms, pos,
     mask_token) | mlp_head (no gradient during pre-training: kept last, outside the AdamW/DP range)
+A bare encoder (classification) puts mlp_head first instead (it is trained, and done first).
 """
 from collections import OrderedDict
 
@@ -69,6 +70,10 @@ class FlatParams:
             tok += [("mask_token", mim.mask_token)]
         groups.append(("tokenizer", tok))
         head = [(f"mlp_head.{n}", p) for n, p in enc.mlp_head.named_parameters()]
+        if mim is None:
+            # bare encoder (classification / finetune.py): the head is trained and its gradients are
+            # the first to complete in the backward
+            return [("cls_head", head)] + groups, []
         return groups, head
 
     def stale(self):
