@@ -208,3 +208,33 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(root, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_load_checkpoint_semantics():
+    """reference src/utils.py:276-313: encoder.* renamed, SimMIM-only keys dropped, classifier Linear replaced
+    by the fresh one, strict load"""
+    from maskedsst_amd import ViTSpatialSpectral
+    from maskedsst_amd.utils import load_checkpoint
+    model, params, _ = build_product(dict(bands=30, depth=1, B=2, heads=2))
+    ckpt = {"model_state_dict": {k: v.clone() for k, v in model.state_dict().items()}}
+    torch.manual_seed(77)
+    enc = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=5, dim=96, depth=1,
+                             heads=2, mlp_dim=64, channels=30, spectral_pos_embed=False, spectral_pos=[0, 1, 2])
+    fresh_w = enc.mlp_head[1].weight.detach().clone()
+
+    class Cfg:
+        patch_sub = 0
+        image_size = 8
+    load_checkpoint(Cfg(), enc, "mlp_head", "cpu", checkpoint=ckpt)
+    sd = enc.state_dict()
+    assert "mask_token" not in sd and not any(k.startswith("to_pixels") for k in sd)
+    assert torch.equal(sd["mlp_head.1.weight"], fresh_w) and sd["mlp_head.1.weight"].shape == (5, 96)
+    for k, v in sd.items():
+        if k.startswith("mlp_head.1"):
+            continue
+        assert torch.equal(v, params["encoder." + k]), k
+    # a checkpoint trained with the other position-embedding mode cannot load (reference quirk, SURVEY 3.3)
+    enc2 = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=5, dim=96, depth=1,
+                              heads=2, mlp_dim=64, channels=30, spectral_pos_embed=True, spectral_pos=[0, 1, 2])
+    with pytest.raises(RuntimeError):
+        load_checkpoint(Cfg(), enc2, "mlp_head", "cpu", checkpoint=ckpt)
