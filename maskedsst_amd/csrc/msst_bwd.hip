@@ -315,13 +315,14 @@ struct AttnBwdSmem {
     static constexpr int LDX = 96 + P::PADE;
     static constexpr int LDH = 64 + P::PADE;
     elem xd[64][LDX];
-    elem q[64][LDH];    // q[row][d]   -> later dq[row][d]
-    elem k[64][LDH];    // k[row][d]   -> later dk[row][d]
-    elem vt[64][LDH];   // vt[d][row]  -> later dv[row][d]
-    elem p[64][LDH];    // p[query][key]
+    // q | k | dO | ds are contiguous: dead after phase C, they receive the staged wqkvT fragments (bf16)
+    elem q[64][LDH];    // q[row][d]
+    elem k[64][LDH];    // k[row][d]
     elem dO[64][LDH];   // dO[query][d]
     elem ds[64][LDH];   // ds[query][key]
-    elem o[64][LDH];    // o[query][d]
+    elem vt[64][LDH];   // vt[d][row]     -> later dv[row][d]
+    elem p[64][LDH];    // p[query][key]  -> later dk[row][d]
+    elem o[64][LDH];    // o[query][d]    -> later dq[row][d]
 };
 
 template <class P>
@@ -391,16 +392,31 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     // (measured: prefetching rows + da + both weight sets needs ~400 registers -> 1 workgroup/CU, slower than
     // 2 workgroups/CU without it; only the cheap parts are enabled)
     constexpr bool BF = sizeof(elem) == 2;
-    constexpr bool PF = false;          // rows / da / weight-fragment prefetch into registers
-    constexpr bool KEEP_XN = BF;        // keep LN1(x) packed (12 registers) instead of recomputing it for phase D
-    constexpr int NKX = PF ? 3 : 1, NKD = PF ? 3 : 1;
+#ifndef MSST_PF_X
+#define MSST_PF_X 0
+#endif
+#ifndef MSST_PF_DA
+#define MSST_PF_DA 0
+#endif
+#ifndef MSST_PF_WA
+#define MSST_PF_WA 0
+#endif
+#ifndef MSST_PF_WDO
+#define MSST_PF_WDO 0
+#endif
+    constexpr bool PF_X = BF && MSST_PF_X;      // next tile's rows requested during phase C      (+24 registers)
+    constexpr bool PF_DA = BF && MSST_PF_DA;    // da rows requested at tile start                (+24)
+    constexpr bool PF_WA = BF && MSST_PF_WA;    // phase-A weight fragments requested at tile start (+36)
+    constexpr bool PF_WDO = BF && MSST_PF_WDO;  // Wout^T fragments requested before S / softmax   (+48)
+    constexpr bool KEEP_XN = BF;                // keep LN1(x) packed (12 registers) instead of recomputing it for phase D
+    constexpr int NKX = PF_WA ? 3 : 1, NKD = PF_WDO ? 3 : 1;
     // LN1 gamma / beta in LDS (tile invariant)
     float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));
     if (tid < 96) { lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; }
     __syncthreads();
     const int lr = tid >> 2, lpart = tid & 3;
     f32x4 xv[6];          // this thread's 24 row values of the tile to process (prefetched one tile ahead)
-    if constexpr (PF) {
+    if constexpr (PF_X) {
         const long tok0 = tm.token_sp(blockIdx.x, sp_ln);
 #pragma unroll
         for (int i = 0; i < 6; ++i) xv[i] = tok0 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok0 * 96 + lpart * 24)[i] : zero4();
@@ -411,41 +427,22 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         f32x4 dav[6];         // da rows of this tile (consumed after phase A)
         frag wa[3][NKX];      // phase-A weight fragments
         s16x4 xnk[6];         // LN1(x) of this thread's 24 features, packed bf16 (re-stored before phase D)
-        if constexpr (PF) {
+        if constexpr (PF_DA) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) dav[i] = tok_ln >= 0 ? reinterpret_cast<const f32x4*>(a.da + tok_ln * 96 + lpart * 24)[i] : zero4();
+        }
+        if constexpr (PF_WA) {
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int ks = 0; ks < NKX; ++ks) wa[m][ks] = P::ld_w(wqkv, 96, (m * H + h) * 64 + wave * 16, ks * 32);
-            // LN1 from the prefetched rows
+        }
+        if constexpr (KEEP_XN) {
             float v[24];
+            if constexpr (PF_X) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
-            float sm1 = 0.f;
-#pragma unroll
-            for (int i = 0; i < 24; ++i) sm1 += v[i];
-            sm1 += __shfl_xor(sm1, 1); sm1 += __shfl_xor(sm1, 2);
-            const float mean = sm1 * (1.f / 96.f);
-            float vs = 0.f;
-#pragma unroll
-            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
-            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
-            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                f32x4 n4;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int d = lpart * 24 + 4 * i + e;
-                    n4[e] = (v[4*i+e] - mean) * rstd * lnp[d] + lnp[96 + d];
-                }
-                xnk[i] = f2bf4(n4);
-                *reinterpret_cast<s16x4*>(&sm.xd[lr][lpart * 24 + 4 * i]) = xnk[i];
-            }
-        } else if constexpr (KEEP_XN) {
-            float v[24];
-            if (tok_ln >= 0) {
+                for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+            } else if (tok_ln >= 0) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok_ln * 96 + lpart * 24);
 #pragma unroll
                 for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
@@ -486,7 +483,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
             for (int t = 0; t < 4; ++t) { cq[t] = zero4(); ck[t] = zero4(); cv[t] = zero4(); }
             const int rq = (0 * H + h) * 64 + wave * 16, rk = (1 * H + h) * 64 + wave * 16, rv = (2 * H + h) * 64 + wave * 16;
-            if constexpr (PF) {
+            if constexpr (PF_WA) {
 #pragma unroll
                 for (int ks = 0; ks < NKX; ++ks) {
 #pragma unroll
@@ -529,7 +526,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 f32x4 t4 = zero4();
-                if constexpr (PF) t4 = dav[i];
+                if constexpr (PF_DA) t4 = dav[i];
                 else if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
                 if (a.drop.thr && tok >= 0) t4 = drop4(a.drop, 2, (unsigned)(tok * 24 + pt * 6 + i), t4);   // site 2 backward
 #pragma unroll
@@ -537,7 +534,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             }
         }
         frag wdo[4][NKD];   // Wout_h^T fragments for the dO GEMM (requested now, used after S / softmax / O)
-        if constexpr (PF) {
+        if constexpr (PF_WDO) {
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -593,7 +590,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);
             }
-            if constexpr (PF) {
+            if constexpr (PF_WDO) {
 #pragma unroll
                 for (int ks = 0; ks < NKD; ++ks) {
                     const frag db = P::ld_kc(&sm.xd[wave * 16][ks * 32], LDX);
@@ -651,57 +648,58 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         lds_barrier();
         STAMP(8);
         // ---------------- phase C: contractions over all 64 queries / keys ----------------
-        if constexpr (PF) {   // rows of the NEXT tile of this workgroup
+        if constexpr (PF_X) {   // rows of the NEXT tile of this workgroup
             const int nt = tile + gridDim.x;
             const long tokn = nt < a.ntiles ? tm.token_sp(nt, sp_ln) : -1;
 #pragma unroll
             for (int i = 0; i < 6; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + lpart * 24)[i] : zero4();
         }
-        f32x4 dq[4], dk[4], dv[4];
+        // C1: dWout_h and dv (reads xd = da, o, p, dO); dv -> vt (dead since phase B)
+        {
+            f32x4 dv[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) { dq[t] = zero4(); dk[t] = zero4(); dv[t] = zero4(); }
+            for (int t = 0; t < 4; ++t) dv[t] = zero4();
 #pragma unroll P::UNROLL
-        for (int k0 = 0; k0 < 64; k0 += KS) {
-            // dWout_h[m][d] += sum_q da[q][m] o[q][d]      C[i = m tile t][j = d tile wave]
-            const frag ob = P::ld_ks(&sm.o[k0][wave * 16], LDH);
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                // dWout_h[m][d] += sum_q da[q][m] o[q][d]      C[i = m tile t][j = d tile wave]
+                const frag ob = P::ld_ks(&sm.o[k0][wave * 16], LDH);
 #pragma unroll
-            for (int t = 0; t < 6; ++t) go[t] = P::mma(P::ld_ks(&sm.xd[k0][t * 16], LDX), ob, go[t]);
-            // dv[key][d] = sum_q p[q][key] dO[q][d]         C[i = d tile t][j = key tile wave]
-            const frag pb = P::ld_ks(&sm.p[k0][wave * 16], LDH);
-            // dk[key][d] = sum_q ds[q][key] q[q][d]         C[i = d tile t][j = key tile wave]
-            const frag sb = P::ld_ks(&sm.ds[k0][wave * 16], LDH);
-            // dq[query][d] = sum_key ds[query][key] k[key][d]   C[i = d tile t][j = query tile wave]
-            const frag sq = P::ld_kc(&sm.ds[wave * 16][k0], LDH);
+                for (int t = 0; t < 6; ++t) go[t] = P::mma(P::ld_ks(&sm.xd[k0][t * 16], LDX), ob, go[t]);
+                // dv[key][d] = sum_q p[q][key] dO[q][d]         C[i = d tile t][j = key tile wave]
+                const frag pb = P::ld_ks(&sm.p[k0][wave * 16], LDH);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                dv[t] = P::mma(P::ld_ks(&sm.dO[k0][t * 16], LDH), pb, dv[t]);
-                dk[t] = P::mma(P::ld_ks(&sm.q[k0][t * 16], LDH), sb, dk[t]);
-                dq[t] = P::mma(P::ld_ks(&sm.k[k0][t * 16], LDH), sq, dq[t]);
+                for (int t = 0; t < 4; ++t) dv[t] = P::mma(P::ld_ks(&sm.dO[k0][t * 16], LDH), pb, dv[t]);
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) P::st_nat(&sm.vt[wave * 16][t * 16], LDH, dv[t]);   // dv[key][d]
         }
         STAMP(9);
         lds_barrier();
         STAMP(10);
-        if constexpr (sizeof(elem) == 2) {
-            // bf16: stage this head's 36 wqkvT fragments (all four waves need all of them in the
-            // d(LN1 out) GEMM) into the dead p|dO|ds|o region with async global->LDS copies, 9 per wave
-            char* stage = reinterpret_cast<char*>(&sm.p[0][0]);
+        // C2: dk -> p, dq -> o (both dead now); LN1(x) rows back into xd for phase D
+        {
+            f32x4 dq[4], dk[4];
 #pragma unroll
-            for (int i9 = 0; i9 < 9; ++i9) {
-                const int idx = wave * 9 + i9;                    // idx = (t * 3 + which) * 2 + ks
-                const int t = idx / 6, which = (idx >> 1) % 3, ks = idx & 1;
-                const int f = t * ((3 * inner) >> 5) + ((which * inner + h * 64 + ks * 32) >> 5);
-                dma_frag(wqkvT + (long)f * 512, stage + idx * 1024);
+            for (int t = 0; t < 4; ++t) { dq[t] = zero4(); dk[t] = zero4(); }
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                // dk[key][d] = sum_q ds[q][key] q[q][d]         C[i = d tile t][j = key tile wave]
+                const frag sb = P::ld_ks(&sm.ds[k0][wave * 16], LDH);
+                // dq[query][d] = sum_key ds[query][key] k[key][d]   C[i = d tile t][j = query tile wave]
+                const frag sq = P::ld_kc(&sm.ds[wave * 16][k0], LDH);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    dk[t] = P::mma(P::ld_ks(&sm.q[k0][t * 16], LDH), sb, dk[t]);
+                    dq[t] = P::mma(P::ld_ks(&sm.k[k0][t * 16], LDH), sq, dq[t]);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                P::st_nat(&sm.p[wave * 16][t * 16], LDH, dk[t]);   // dk[key][d]
+                P::st_nat(&sm.o[wave * 16][t * 16], LDH, dq[t]);   // dq[query][d]
             }
         }
-        // dq / dk / dv over the dead q / k / vt buffers, all as [row][d]
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            P::st_nat(&sm.q[wave * 16][t * 16], LDH, dq[t]);
-            P::st_nat(&sm.k[wave * 16][t * 16], LDH, dk[t]);
-            P::st_nat(&sm.vt[wave * 16][t * 16], LDH, dv[t]);
-        }
-        if constexpr (PF || KEEP_XN) {
+        if constexpr (KEEP_XN) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) *reinterpret_cast<s16x4*>(&sm.xd[lr][lpart * 24 + 4 * i]) = xnk[i];
         } else {
@@ -710,12 +708,24 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         STAMP(11);
         lds_barrier();
         STAMP(12);
+        if constexpr (sizeof(elem) == 2) {
+            // bf16: stage this head's 36 wqkvT fragments (all four waves need all of them in the d(LN1 out)
+            // GEMM) into the dead q|k|dO|ds region with async global->LDS copies, 9 per wave
+            char* stage = reinterpret_cast<char*>(&sm.q[0][0]);
+#pragma unroll
+            for (int i9 = 0; i9 < 9; ++i9) {
+                const int idx = wave * 9 + i9;                    // idx = (t * 3 + which) * 2 + ks
+                const int t = idx / 6, which = (idx >> 1) % 3, ks = idx & 1;
+                const int f = t * ((3 * inner) >> 5) + ((which * inner + h * 64 + ks * 32) >> 5);
+                dma_frag(wqkvT + (long)f * 512, stage + idx * 1024);
+            }
+        }
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
 #pragma unroll P::UNROLL
         for (int k0 = 0; k0 < 64; k0 += KS) {
             // dW{q,k,v}[d][m] += sum_row d{q,k,v}[row][d] xn[row][m]    C[i = d tile wave][j = m tile t]
-            const frag aq = P::ld_ks(&sm.q[k0][wave * 16], LDH);
-            const frag ak = P::ld_ks(&sm.k[k0][wave * 16], LDH);
+            const frag aq = P::ld_ks(&sm.o[k0][wave * 16], LDH);
+            const frag ak = P::ld_ks(&sm.p[k0][wave * 16], LDH);
             const frag av = P::ld_ks(&sm.vt[k0][wave * 16], LDH);
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
@@ -736,13 +746,13 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             STAMP(14);   // every wave is done reading xd (weight-grad loop above); staged weights visible
 #pragma unroll P::UNROLL
             for (int k0 = 0; k0 < 64; k0 += KS) {
-                const frag bq = P::ld_kc(&sm.q[wave * 16][k0], LDH);
-                const frag bk = P::ld_kc(&sm.k[wave * 16][k0], LDH);
+                const frag bq = P::ld_kc(&sm.o[wave * 16][k0], LDH);
+                const frag bk = P::ld_kc(&sm.p[wave * 16][k0], LDH);
                 const frag bv = P::ld_kc(&sm.vt[wave * 16][k0], LDH);
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
                     if constexpr (sizeof(elem) == 2) {
-                        const char* stage = reinterpret_cast<const char*>(&sm.p[0][0]) + l * 16;
+                        const char* stage = reinterpret_cast<const char*>(&sm.q[0][0]) + l * 16;
                         const int ks = k0 >> 5;
                         dx[t] = P::mma(*reinterpret_cast<const frag*>(stage + ((t * 3 + 0) * 2 + ks) * 1024), bq, dx[t]);
                         dx[t] = P::mma(*reinterpret_cast<const frag*>(stage + ((t * 3 + 1) * 2 + ks) * 1024), bk, dx[t]);
