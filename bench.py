@@ -170,8 +170,15 @@ def main():
             fl = ntok * 0.5 * (per[dom](N) + per[dom](S))
             avg_s = cand[dom]["avg_us"] * 1e-6
             achieved = fl / avg_s / 1e12
+            traffic = None   # HBM bytes per launch from the committed PMC passes of this same command (profiles/)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                if B == 256 and args.bands == 200 and args.depth == 12 and args.precision == "bf16":
+                    traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
-                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                               "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                                "avg_launch_us": round(cand[dom]["avg_us"], 2),
                                "algorithmic_gflop_per_launch": round(fl / 1e9, 3)}
             out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
