@@ -129,7 +129,44 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     }
     float dbias = 0.f;  // tid < 96: db2[tid]; 96 <= tid < 160: db1[tid - 96]
 
+    // tile-invariant small vectors in LDS: ln2_g | ln2_b | b1
+    float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));
+    if (tid < 96) { lnp[tid] = a.w.ln2_g[tid]; lnp[96 + tid] = a.w.ln2_b[tid]; if (tid < 64) lnp[192 + tid] = a.w.b1[tid]; }
+    // bf16: the three weight matrices (36 fragment-packed KB) stay in LDS for the life of the workgroup and the
+    // next tile's rows are requested one tile ahead (this kernel runs 1 wave/SIMD: registers are plentiful)
+    constexpr bool BF = sizeof(elem) == 2;
+    char* wl = smem_raw + sizeof(SM) + 256 * sizeof(float);   // [w1 12 | w2T 12 | w1T 12] fragments of 1 KB
+    if constexpr (BF) {
+#pragma unroll
+        for (int i9 = 0; i9 < 9; ++i9) {
+            const int f = wave * 9 + i9;
+            const char* src = f < 12 ? reinterpret_cast<const char*>(w1) + f * 1024
+                            : f < 24 ? reinterpret_cast<const char*>(w2T) + (f - 12) * 1024
+                                     : reinterpret_cast<const char*>(w1T) + (f - 24) * 1024;
+            dma_frag(src, wl + f * 1024);
+        }
+        wait_vm0();
+    }
+    __syncthreads();
+    auto wfrag = [&](int which, const elem* wg, int K, int row0, int k0) -> frag {
+        if constexpr (BF) {
+            const int f = which * 12 + (row0 >> 4) * (K >> 5) + (k0 >> 5);
+            return *reinterpret_cast<const frag*>(wl + f * 1024 + l * 16);
+        } else {
+            return P::ld_w(wg, K, row0, k0);
+        }
+    };
+
     const int ntiles = (a.ntok + 63) / 64;
+    f32x4 xpre[6], dpre[6];
+    if constexpr (BF) {
+        const long tok0 = (long)blockIdx.x * 64 + wave * 16 + c;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            xpre[mt] = tok0 < a.ntok ? *reinterpret_cast<const f32x4*>(a.x1 + tok0 * 96 + mt * 16 + 4 * g) : zero4();
+            dpre[mt] = tok0 < a.ntok ? *reinterpret_cast<const f32x4*>(a.dy + tok0 * 96 + mt * 16 + 4 * g) : zero4();
+        }
+    }
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long tok = (long)tile * 64 + wave * 16 + c;
         const bool valid = tok < a.ntok;
@@ -139,7 +176,13 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int mt = 0; mt < 6; ++mt) {
             const int m0 = mt * 16 + 4 * g;
             f32x4 xr = zero4(), dr = zero4();
-            if (valid) {
+            if constexpr (BF) {
+                xr = xpre[mt]; dr = dpre[mt];
+                const long tokn = tok + (long)gridDim.x * 64;   // same rows of this workgroup's next tile
+                const bool vn = tile + (int)gridDim.x < ntiles && tokn < a.ntok;
+                xpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.x1 + tokn * 96 + m0) : zero4();
+                dpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.dy + tokn * 96 + m0) : zero4();
+            } else if (valid) {
                 xr = *reinterpret_cast<const f32x4*>(a.x1 + tok * 96 + m0);
                 dr = *reinterpret_cast<const f32x4*>(a.dy + tok * 96 + m0);
             }
@@ -165,7 +208,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 xhat[mt][r] = (xhat[mt][r] - mean) * rstd;
-                n4[r] = xhat[mt][r] * a.w.ln2_g[m0 + r] + a.w.ln2_b[m0 + r];
+                n4[r] = xhat[mt][r] * lnp[m0 + r] + lnp[96 + m0 + r];
             }
             P::st_nat(&sm.xn2[wave * 16][mt * 16], LDX, n4);
         }
@@ -180,8 +223,8 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             const frag db = P::ld_kc(&sm.dy[wave * 16][k0], LDX);
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                hp[nt] = P::mma(P::ld_w(w1, 96, nt * 16, k0), xb, hp[nt]);
-                dh[nt] = P::mma(P::ld_w(w2T, 96, nt * 16, k0), db, dh[nt]);
+                hp[nt] = P::mma(wfrag(0, w1, 96, nt * 16, k0), xb, hp[nt]);
+                dh[nt] = P::mma(wfrag(1, w2T, 96, nt * 16, k0), db, dh[nt]);
             }
         }
 #pragma unroll
@@ -192,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             if (a.drop.thr && valid) dhm = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), dhm);   // site 3 backward
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float pre = hp[nt][r] + a.w.b1[n0 + r];
+                const float pre = hp[nt][r] + lnp[192 + n0 + r];
                 hv[r] = P::gelu(pre);
                 dv[r] = dhm[r] * P::gelu_grad(pre);
             }
@@ -209,7 +252,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int k0 = 0; k0 < 64; k0 += KS) {
             const frag hb = P::ld_kc(&sm.dhp[wave * 16][k0], LDH);
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(P::ld_w(w1T, 64, mt * 16, k0), hb, dxn[mt]);
+            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(wfrag(2, w1T, 64, mt * 16, k0), hb, dxn[mt]);
         }
         // LN2 backward + residual
         float g1 = 0.f, g2 = 0.f;
@@ -221,7 +264,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
                 const float dn = dxn[mt][r];
                 dgam[mt][r] += dn * xhat[mt][r];
                 dbet[mt][r] += dn;
-                const float dg = dn * a.w.ln2_g[m0 + r];
+                const float dg = dn * lnp[m0 + r];
                 dxn[mt][r] = dg;
                 g1 += dg;
                 g2 += dg * xhat[mt][r];
@@ -239,7 +282,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
                 *reinterpret_cast<f32x4*>(a.dx1 + tok * 96 + m0) = o4;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---------------- phase 2: weight grads over the 64 rows of the tile ----------------
 #pragma unroll P::UNROLL
         for (int k0 = 0; k0 < 64; k0 += KS) {
@@ -260,7 +303,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             for (int r = 0; r < 64; ++r) s += P::up(sm.dhp[r][tid - 96]);
             dbias += s;
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     // ---------------- write this workgroup's slab ----------------
@@ -1098,13 +1141,13 @@ static int set_smem(K kernel, size_t smem, bool& done) {
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st) {
     static bool d0 = false, d1 = false;
     if (prec == MSST_PREC_F32) {
-        const size_t smem = sizeof(MlpBwdSmem<PF32>);
+        const size_t smem = sizeof(MlpBwdSmem<PF32>) + 256 * sizeof(float);
         int rc = set_smem(&block_bwd_mlp_kernel<PF32>, smem, d0);
         if (rc) return rc;
         ProfScope ps(K_BWD_MLP, st);
         hipLaunchKernelGGL(block_bwd_mlp_kernel<PF32>, dim3(grid), dim3(256), smem, st, a);
     } else {
-        const size_t smem = sizeof(MlpBwdSmem<PBF16>);
+        const size_t smem = sizeof(MlpBwdSmem<PBF16>) + 256 * sizeof(float) + 36 * 1024;
         int rc = set_smem(&block_bwd_mlp_kernel<PBF16>, smem, d1);
         if (rc) return rc;
         ProfScope ps(K_BWD_MLP, st);
