@@ -30,7 +30,8 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=()):
+    """extra_flags: e.g. ("-DMSST_STAMPS",) for the kernel-study builds used by tools/stamps*.py"""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
     objdir = os.path.join(HERE, "build")
@@ -40,7 +41,7 @@ def build(force=False, verbose=False):
     def compile_one(src):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         if force or _stale(obj, [src] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", src, "-o", obj]
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)
@@ -61,4 +62,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv or "--stamps" in sys.argv, verbose=True,
+                extra_flags=("-DMSST_STAMPS",) if "--stamps" in sys.argv else ()))

@@ -426,11 +426,10 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     const int2 sp_ln = tm.row_sp(tid >> 2);
     const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;
     constexpr int CPR = 96 * (int)sizeof(elem) / 16;   // 16-byte chunks per row (copy-out of the partial)
-    int2 sp_out[(16 * CPR) / 64];
-#pragma unroll
-    for (int it = 0; it < (16 * CPR) / 64; ++it) sp_out[it] = tm.row_sp(wave * 16 + (it * 64 + l) / CPR);
 
+#ifdef MSST_STAMPS
     const bool stamp_on = (a.dbg & 8) && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0;
+#endif
     // bf16: software prefetch (global round trips are ~2k cycles under load); fp32 keeps the simple loads
     // (measured: prefetching rows + da + both weight sets needs ~400 registers -> 1 workgroup/CU, slower than
     // 2 workgroups/CU without it; only the cheap parts are enabled)
@@ -815,7 +814,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
             for (int it = 0; it < (16 * CPR) / 64; ++it) {
                 const int idx = it * 64 + l, rr = idx / CPR, ch = idx - rr * CPR;
-                const long tok = tm.token_sp(tile, sp_out[it]);
+                const long tok = tm.token(tile, wave * 16 + rr);
                 if (tok >= 0) {
                     const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(&sm.xd[wave * 16 + rr][0]) + ch * 16);
                     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(part + tok * 96) + ch * 16) = v;

@@ -193,7 +193,12 @@ __device__ __forceinline__ void dma_frag(const void* gsrc_frag, void* lds_dst_fr
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// kernel-study cycle stamps are compiled in only with -DMSST_STAMPS (tools/stamps*.py); production builds carry none
+#ifdef MSST_STAMPS
 #define STAMP(i) do { if (stamp_on) { a.stamps[(i)] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Dropout (reference sites vit_spatial_spectral.py:38,40,57,62).  Counter-based, stateless: the keep

@@ -122,7 +122,9 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
     const int2 sp_ep = tm.row_sp(wave * 16 + c);     // row handled in the epilogue
     const int qlo = ((wave * 16 + c) / L) * L, qhi = qlo + L;   // keys of the query row's own sequence
 
+#ifdef MSST_STAMPS
     const bool stamp_on = (a.dbg & 8) && blockIdx.x == (unsigned)(a.ntiles / 2) && tid == 0;
+#endif
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         STAMP(0);
@@ -411,7 +413,9 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
         for (int i = 0; i < 6; ++i) xv[i] = tok >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24)[i] : zero4();
     }
 
+#ifdef MSST_STAMPS
     const bool stamp_on = (a.dbg & 8) && blockIdx.x == 100 && tid == 0;
+#endif
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         STAMP(0);
         // phase-A weights of head 0 (q, k, v rows of this wave's 16 channels; 3 k-steps each)

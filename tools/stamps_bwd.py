@@ -1,5 +1,6 @@
 """kernel study: cycle stamps of one wave of block_bwd_attn (MSST_DBG=8)."""
 import os, sys, ctypes
+# needs a stamps build first:  python -m maskedsst_amd.build --stamps   (rebuild with --force afterwards)
 os.environ["MSST_DBG"] = "8"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
