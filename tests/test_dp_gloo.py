@@ -66,7 +66,7 @@ def _worker(rank, world, port, q):
         t = torch.tensor([loss], dtype=torch.float64)
         dist.all_reduce(t)
         if rank == 0:
-            q.put((t.item() / world, (fp.grad[: fp.n_trainable] * scale).clone(), dict(flat_names),
+            q.put((t.item() / world, (fp.grad[: fp.n_trainable] * scale).numpy().copy(), dict(flat_names),
                    {n: fp.segments[n] for n in flat_names}))
     finally:
         dist.destroy_process_group()
@@ -81,6 +81,7 @@ def test_two_rank_gloo_matches_single_process():
     for p in procs:
         p.start()
     loss_dp, flat, names, segs = q.get(timeout=240)
+    flat = torch.from_numpy(flat)   # sent by value (numpy): the worker may exit before a shared-fd tensor is rebuilt
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
