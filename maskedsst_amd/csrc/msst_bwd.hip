@@ -565,11 +565,18 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         {
             const int r = tid >> 2, pt = tid & 3;
             const long tok = tok_ln;
+            f32x4 dl[6];   // all six requests in flight before the first use (one memory round trip, not six)
+            if constexpr (PF_DA) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dl[i] = dav[i];
+            } else {
+                const f32x4* src = reinterpret_cast<const f32x4*>(a.da + (tok >= 0 ? tok : 0) * 96 + pt * 24);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dl[i] = src[i];
+            }
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                f32x4 t4 = zero4();
-                if constexpr (PF_DA) t4 = dav[i];
-                else if (tok >= 0) t4 = reinterpret_cast<const f32x4*>(a.da + tok * 96 + pt * 24)[i];
+                f32x4 t4 = tok >= 0 ? dl[i] : zero4();
                 if (a.drop.thr && tok >= 0) t4 = drop4(a.drop, 2, (unsigned)(tok * 24 + pt * 6 + i), t4);   // site 2 backward
 #pragma unroll
                 for (int e = 0; e < 4; ++e) sm.xd[r][pt * 24 + 4 * i + e] = P::cvt(t4[e]);
@@ -643,9 +650,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll P::UNROLL
                 for (int k0 = 0; k0 < 96; k0 += KS) {
                     const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
+                    frag wf[4];   // the four requests go out together
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        dov[t] = P::mma(P::ld_w(woutT, 96, h * 64 + t * 16, k0), db, dov[t]);
+                    for (int t = 0; t < 4; ++t) wf[t] = P::ld_w(woutT, 96, h * 64 + t * 16, k0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dov[t] = P::mma(wf[t], db, dov[t]);
                 }
             }
 #pragma unroll
@@ -812,12 +821,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             for (int t = 0; t < 6; ++t) P::st_nat(&sm.xd[wave * 16][t * 16], LDX, dx[t]);
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < (16 * CPR) / 64; ++it) {
-                const int idx = it * 64 + l, rr = idx / CPR, ch = idx - rr * CPR;
-                const long tok = tm.token(tile, wave * 16 + rr);
-                if (tok >= 0) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(&sm.xd[wave * 16 + rr][0]) + ch * 16);
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(part + tok * 96) + ch * 16) = v;
+            for (int i = 0; i < CPR / 4; ++i) {   // thread <-> (row tid / 4, quarter tid % 4) as in LN1: address already known
+                if (tok_ln >= 0) {
+                    const int ch = lpart * (CPR / 4) + i;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(&sm.xd[lr][0]) + ch * 16);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(part + tok_ln * 96) + ch * 16) = v;
                 }
             }
         }
