@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     constexpr int KS = P::KS, LDX = SM::LDX, LDH = SM::LDH;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SM& sm = *reinterpret_cast<SM*>(smem_raw);
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
     const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
     const elem* w1T = reinterpret_cast<const elem*>(a.w.w1T);
     const elem* w2T = reinterpret_cast<const elem*>(a.w.w2T);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SM& sm = *reinterpret_cast<SM*>(smem_raw);
 
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
     const int H = a.H, inner = H * 64, h = blockIdx.y;
     const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
     const elem* wqkvT = reinterpret_cast<const elem*>(a.w.wqkvT);
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     constexpr int NKX = PF_WA ? 3 : 1, NKD = PF_WDO ? 3 : 1;
     // LN1 gamma / beta in LDS (tile invariant)
     float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));
+    void* touch_pad = lnp + 192;   // 256 B nobody reads (l2_touch target)
     if (tid < 96) { lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; }
     __syncthreads();
     const int lr = tid >> 2, lpart = tid & 3;
@@ -478,6 +479,12 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             for (int m = 0; m < 3; ++m)
 #pragma unroll
                 for (int ks = 0; ks < NKX; ++ks) wa[m][ks] = P::ld_w(wqkv, 96, (m * H + h) * 64 + wave * 16, ks * 32);
+        }
+        frag wa0[3];          // bf16: first k-step of the phase-A weights, requested under the row loads
+        if constexpr (BF && !PF_WA) {
+            if constexpr (!PF_DA) l2_touch(a.da + (tok_ln >= 0 ? tok_ln : 0) * 96 + lpart * 24, touch_pad);
+#pragma unroll
+            for (int m = 0; m < 3; ++m) wa0[m] = P::ld_w(wqkv, 96, (m * H + h) * 64 + wave * 16, 0);
         }
         if constexpr (KEEP_XN) {
             float v[24];
@@ -535,6 +542,25 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                         ck[t] = P::mma(wa[1][ks], xb, ck[t]);
                         cv[t] = P::mma(xb, wa[2][ks], cv[t]);
                     }
+                }
+            } else if constexpr (BF) {
+                frag cur[3] = {wa0[0], wa0[1], wa0[2]};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {   // next k-step's fragments are in flight under this one's MFMAs
+                    frag nxt[3];
+                    if (ks < 2) {
+                        nxt[0] = P::ld_w(wqkv, 96, rq, (ks + 1) * 32);
+                        nxt[1] = P::ld_w(wqkv, 96, rk, (ks + 1) * 32);
+                        nxt[2] = P::ld_w(wqkv, 96, rv, (ks + 1) * 32);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const frag xb = P::ld_kc(&sm.xd[t * 16][ks * 32], LDX);
+                        cq[t] = P::mma(cur[0], xb, cq[t]);
+                        ck[t] = P::mma(cur[1], xb, ck[t]);
+                        cv[t] = P::mma(xb, cur[2], cv[t]);
+                    }
+                    if (ks < 2) { cur[0] = nxt[0]; cur[1] = nxt[1]; cur[2] = nxt[2]; }
                 }
             } else {
 #pragma unroll P::UNROLL
@@ -633,6 +659,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             f32x4 o[4], dov[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) { o[t] = zero4(); dov[t] = zero4(); }
+            frag wd0[4];   // bf16: first k-step of Wout_h^T, requested under o = P v
+            if constexpr (BF && !PF_WDO) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) wd0[t] = P::ld_w(woutT, 96, h * 64 + t * 16, 0);
+            }
 #pragma unroll P::UNROLL
             for (int k0 = 0; k0 < 64; k0 += KS) {
                 const frag pb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
@@ -647,14 +678,32 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                     for (int t = 0; t < 4; ++t) dov[t] = P::mma(wdo[t][ks], db, dov[t]);
                 }
             } else {
+                if constexpr (BF) {
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {   // next k-step's four fragments in flight under this one's MFMAs
+                        frag nx[4];
+                        if (ks < 2) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) nx[t] = P::ld_w(woutT, 96, h * 64 + t * 16, (ks + 1) * 32);
+                        }
+                        const frag db = P::ld_kc(&sm.xd[wave * 16][ks * 32], LDX);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) dov[t] = P::mma(wd0[t], db, dov[t]);
+                        if (ks < 2) {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) wd0[t] = nx[t];
+                        }
+                    }
+                } else {
 #pragma unroll P::UNROLL
-                for (int k0 = 0; k0 < 96; k0 += KS) {
-                    const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
-                    frag wf[4];   // the four requests go out together
+                    for (int k0 = 0; k0 < 96; k0 += KS) {
+                        const frag db = P::ld_kc(&sm.xd[wave * 16][k0], LDX);
+                        frag wf[4];   // the four requests go out together
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) wf[t] = P::ld_w(woutT, 96, h * 64 + t * 16, k0);
+                        for (int t = 0; t < 4; ++t) wf[t] = P::ld_w(woutT, 96, h * 64 + t * 16, k0);
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dov[t] = P::mma(wf[t], db, dov[t]);
+                        for (int t = 0; t < 4; ++t) dov[t] = P::mma(wf[t], db, dov[t]);
+                    }
                 }
             }
 #pragma unroll
@@ -704,6 +753,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             const long tokn = nt < a.ntiles ? tm.token_sp(nt, sp_ln) : -1;
 #pragma unroll
             for (int i = 0; i < 6; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + lpart * 24)[i] : zero4();
+        }
+        if constexpr (BF && !PF_X) {   // warm the L2 with the NEXT tile's rows (the LN1 loads are the longest stall)
+            const int nt = tile + gridDim.x;
+            const long tokn = nt < a.ntiles ? tm.token_sp(nt, sp_ln) : -1;
+            l2_touch(a.x + (tokn >= 0 ? tokn : 0) * 96 + lpart * 24, touch_pad);
         }
         // C1: dWout_h and dv (reads xd = da, o, p, dO); dv -> vt (dead since phase B)
         {
@@ -768,7 +822,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 const int idx = wave * 9 + i9;                    // idx = (t * 3 + which) * 2 + ks
                 const int t = idx / 6, which = (idx >> 1) % 3, ks = idx & 1;
                 const int f = t * ((3 * inner) >> 5) + ((which * inner + h * 64 + ks * 32) >> 5);
-                dma_frag(wqkvT + (long)f * 512, stage + idx * 1024);
+                dma_frag_async(wqkvT + (long)f * 512, stage + idx * 1024);
             }
         }
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------

@@ -19,6 +19,7 @@
 
 namespace msst {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -114,8 +115,12 @@ struct PBF16 {
     // msst_prep_weights: the 1 KB fragment (16 rows x 32 k) f = (row0/16)*(K/32) + k0/32 is contiguous
     // in lane order, so one global_load_dwordx4 per lane reads 8 full cache lines instead of 16 halves.
     static __device__ __forceinline__ frag ld_w(const elem* w, int K, int row0, int k0) {
+        // Buffer load: descriptor (w) and fragment offset live in SGPRs (row0 / k0 are wave uniform in every
+        // caller), the only VGPR is the lane offset shared by all weight loads -- no 64-bit address pair per fragment.
         const int f = (row0 >> 4) * (K >> 5) + (k0 >> 5);
-        return *reinterpret_cast<const s16x8*>(w + ((long)f * 64 + lane_id()) * 8);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(w), 0, 0x7fffffff, 0x00020000);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, lane_id() * 16, f * 1024, 0);
+        return __builtin_bit_cast(s16x8, v);
     }
     // k-strided operand in LDS: element (row, k) at p[k*ld + row].  Two ds_read_b64_tr_b16: the 16
     // lanes of a group fetch a [4 k][16 row] block (lane i supplies the address of k-row i>>2,
@@ -190,6 +195,21 @@ __device__ __forceinline__ void dma_frag(const void* gsrc_frag, void* lds_dst_fr
     const char* src = reinterpret_cast<const char*>(gsrc_frag) + lane_id() * 16;
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst_frag, 16, 0, 0);
+}
+// Same copy, but opaque to the compiler: a builtin LDS-DMA makes it wait (vmcnt(0)) before ANY later LDS read,
+// which serialises the copy with the GEMM it is meant to run under.  The caller orders the consumers itself
+// with wait_vm0() + lds_barrier().  lds_dst_frag must be wave uniform.
+__device__ __forceinline__ void dma_frag_async(const void* gsrc_frag, void* lds_dst_frag) {
+    const char* src = reinterpret_cast<const char*>(gsrc_frag) + lane_id() * 16;
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst_frag;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
+}
+// Pull the 128-byte line holding p towards this XCD's L2 without tying up a register: a 4-byte LDS-DMA into a
+// 256-byte scratch area nobody reads.  Counts in vmcnt like any load (in-order return), so place it where the
+// next vmcnt wait belongs to a request of similar latency.
+__device__ __forceinline__ void l2_touch(const void* p, void* lds_dummy) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dummy;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dword %1, off" :: "s"(dst), "v"(p) : "memory", "m0");
 }
 __device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, P::WAVES_PER_SIMD) void block_fwd_kernel(Block
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SM& sm = *reinterpret_cast<SM*>(smem_raw);
 
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
     const int H = a.H, inner = H * 64;
     const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
     const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SM& sm = *reinterpret_cast<SM*>(smem_raw);
 
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63, g = l >> 4, c = l & 15;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
     const int H = a.H, inner = H * 64;
     const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
     const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
