@@ -163,6 +163,8 @@ int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * the launch count since enable / the previous collect.  Not thread-safe; meant for bench.py. */
 int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tools/stamps.py */);
 int msst_profile_enable(int on);
+/* restrict the event pairs to the kernel ids whose bit is set (default: all); each pair costs ~10 us of stream time */
+int msst_profile_select(unsigned long long mask);
 int msst_profile_kernels(void);
 const char* msst_profile_name(int id);
 int msst_profile_collect(double* total_ms /*host*/, long* count /*host*/);

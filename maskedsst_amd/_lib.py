@@ -59,6 +59,7 @@ _SIGS = {
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),
     "msst_profile_enable": (c_int, [c_int]),
+    "msst_profile_select": (c_int, [ctypes.c_ulonglong]),
     "msst_profile_kernels": (c_int, []),
     "msst_profile_name": (c_char_p, [c_int]),
     "msst_profile_collect": (c_int, [_P, _P]),

@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
 struct ProfRec { int id; hipEvent_t a, b; };
 static unsigned long long* g_stamps = nullptr;
 static bool g_prof_on = false;
+static unsigned long long g_prof_mask = ~0ull;   // kernels (bit = id) that get event pairs
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 static size_t g_pool_next = 0;
@@ -66,7 +67,7 @@ static hipEvent_t pool_event() {
 }
 
 void prof_begin(int id, hipStream_t st) {
-    if (!g_prof_on) return;
+    if (!g_prof_on || !((g_prof_mask >> id) & 1ull)) return;
     ProfRec r;
     r.id = id; r.a = pool_event(); r.b = pool_event();
     hipEventRecord(r.a, st);
@@ -129,6 +130,8 @@ int msst_profile_enable(int on) {
     if (on) { g_prof.clear(); g_pool_next = 0; g_open = nullptr; }
     return 0;
 }
+
+int msst_profile_select(unsigned long long mask) { g_prof_mask = mask; return 0; }
 
 int msst_profile_kernels(void) { return K_COUNT; }
 

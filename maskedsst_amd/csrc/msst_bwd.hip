@@ -435,7 +435,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     // 2 workgroups/CU without it; only the cheap parts are enabled)
     constexpr bool BF = sizeof(elem) == 2;
 #ifndef MSST_PF_X
-#define MSST_PF_X 0
+#define MSST_PF_X 1
 #endif
 #ifndef MSST_PF_DA
 #define MSST_PF_DA 0

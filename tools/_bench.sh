@@ -1,5 +1,5 @@
 mkdir -p gpurun_out
-timeout 900 python bench.py --steps 5 --warmup 2 --batch 256 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_cur.txt
+timeout 900 python bench.py --steps 5 --warmup 2 --batch 256 --no-cpu-baseline --profile-all 2>&1 | tail -1 > gpurun_out/bench_cur.txt
 python - <<PY
 import json
 d=json.loads(open("gpurun_out/bench_cur.txt").read())

@@ -1,5 +1,5 @@
 for d in 0.0 0.1; do
-timeout 900 python bench.py --steps 5 --warmup 2 --batch 256 --no-cpu-baseline --dropout $d 2>&1 | tail -1 > /tmp/b.json
+timeout 900 python bench.py --steps 5 --warmup 2 --batch 256 --no-cpu-baseline --profile-all --dropout $d 2>&1 | tail -1 > /tmp/b.json
 python - <<PY
 import json
 d=json.loads(open("/tmp/b.json").read())
