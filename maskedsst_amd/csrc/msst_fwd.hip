@@ -771,6 +771,17 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
         const int grid = a.ntiles < a.max_grid ? a.ntiles : a.max_grid;
         return prec == MSST_PREC_F32 ? launch_block_fwd_t<PF32>(a, grid, st) : launch_block_fwd_t<PBF16>(a, grid, st);
     }
+    if (a.H == 8 && !(a.dbg & 64)) {   // head-per-wave kernel: one 512-thread workgroup per CU walks the tiles
+        static int ncu = 0;
+        if (!ncu) {
+            int dev = 0;
+            hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+        }
+        int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
+        if (grid > ncu) grid = ncu;
+        return launch_block_fwd_hw(a, grid, st);
+    }
     // persistent grid: 2 workgroups per CU (LDS 50 KB, <= 256 VGPRs)
     int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
     if (grid > 512) grid = 512;

@@ -1,0 +1,450 @@
+// bf16 forward of one transformer block, head-per-wave (reference vit_spatial_spectral.py:22-104:
+// PreNorm + Attention + residual, PreNorm + FeedForward + residual; a7-a10 of SURVEY.md section 8).
+//
+// Same math, same dropout streams and the same HBM interface as block_fwd_bf16_kernel (msst_fwd.hip);
+// what changes is who does what on the CU:
+//   * one 512-thread workgroup per CU, wave h <-> attention head h of the current 64-row tile;
+//   * a wave computes q, k, v of ITS head straight into MFMA operand registers and keeps the whole
+//     attention (S, softmax, P, O, out-projection of the head) in registers: the C-layout result of one
+//     MFMA is fed to the next one as a B (or A) operand by packing two 16-row C tiles into one 32-deep
+//     k-chunk.  That permutes the contraction index inside the chunk, which is harmless as long as the
+//     other operand uses the same permutation -- for q.k^T and P.V both operands are built the same way;
+//     for the out-projection the rows of W_v are gathered so that O comes out in natural order.
+//   * no barrier and no LDS round trip between LN1 and the end of the out-projection (the tuned
+//     4-wave kernel has two barriers and five LDS round trips per head);
+//   * the 8 per-head out-projection partials meet in four fp32 LDS tiles in a fixed order (waves 0-3
+//     store, waves 4-7 add on top, the row-wise epilogue adds the four) -- ds_add_f32 was measured at
+//     ~160 cycles per instruction on gfx950 and is not used.
+#include "msst_dev.h"
+#include "msst_kernels.h"
+
+#ifndef MSST_F2_STAMP_TID
+#define MSST_F2_STAMP_TID 0
+#endif
+#ifndef MSST_F2_RING
+#define MSST_F2_RING 4
+#endif
+
+namespace msst {
+
+namespace {
+
+typedef PBF16 P;
+typedef bf16_t elem;
+typedef s16x8 frag;
+
+struct Fwd2Smem {
+    static constexpr int LDX = 96 + 8;    // bf16 rows of 96 (+16 B pad: conflict-free b128 fragment reads)
+    static constexpr int LDH = 64 + 8;
+    static constexpr int LDA = 64 + 4;    // fp32 [feature][row]: lane (c, g) -> bank 16 g + c for the atomics
+    elem xn[64][LDX];                     // LN1(x), later LN2(x1)
+    float pbuf[4][96][LDA];               // out-projection partials of head pairs (h, h + 4); [0] later holds x1
+    elem hb[64][LDH];                     // GELU(W1 .) of the MLP
+};
+
+__device__ __forceinline__ frag pack2(f32x4 lo, f32x4 hi) {
+    const s16x4 a = f2bf4(lo), b = f2bf4(hi);
+    frag r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// fragment of 16 GATHERED rows of a fragment-packed [R][K] weight: lane column c reads row
+// row32 + 8 (c / 4) + c % 4 + 4 hi  (voff carries the lane part, see below)
+__device__ __forceinline__ frag ld_w_gather(const elem* w, int K, int row32, int k0, int voff) {
+    const int f = (row32 >> 4) * (K >> 5) + (k0 >> 5);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(w), 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, f * 1024, 0);
+    return __builtin_bit_cast(frag, v);
+}
+
+// weight-fragment pair number pi of head h (compile-time constant after unrolling): the stream a wave consumes per tile is
+//   0..5 q   6..11 k   (pair = fragments of channel tiles 2m, 2m+1 at k-step ks; pi = 3 (2 which + m) + ks)
+//   12..17 gathered v  (pair = low / high channel halves of block mm at k-step ks; pi = 12 + 3 mm + ks)
+//   18..23 out-projection slice (pair = the two 32-channel chunks of feature tile mt = pi - 18)
+__device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wqkv, const elem* wout, int H, int h,
+                                          const int (&voff)[2]) {
+    if (pi < 12) {
+        const int st = pi / 3, ks = pi % 3;
+        const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
+        out[0] = P::ld_w(wqkv, 96, r0, ks * 32);
+        out[1] = P::ld_w(wqkv, 96, r0 + 16, ks * 32);
+    } else if (pi < 18) {
+        const int mm = (pi - 12) / 3, ks = (pi - 12) % 3;
+        const int r32 = (2 * H + h) * 64 + mm * 32;
+        out[0] = ld_w_gather(wqkv, 96, r32, ks * 32, voff[0]);
+        out[1] = ld_w_gather(wqkv, 96, r32, ks * 32, voff[1]);
+    } else {
+        out[0] = P::ld_w(wout, H * 64, (pi - 18) * 16, h * 64);
+        out[1] = P::ld_w(wout, H * 64, (pi - 18) * 16, h * 64 + 32);
+    }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
+    typedef Fwd2Smem SM;
+    constexpr int LDX = SM::LDX, LDH = SM::LDH, LDA = SM::LDA;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
+    const int H = a.H, inner = H * 64, h = wave;
+    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
+    const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
+    const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
+    const elem* w2 = reinterpret_cast<const elem*>(a.w.w2);
+    const TileMap tm = a.tm;
+    const int L = tm.L;
+
+    // small parameter vectors and the MLP weights stay in LDS for the life of the workgroup
+    float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));   // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1
+    if (tid < 96) {
+        lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; lnp[192 + tid] = a.w.bo[tid];
+        lnp[288 + tid] = a.w.ln2_g[tid]; lnp[384 + tid] = a.w.ln2_b[tid]; lnp[480 + tid] = a.w.b2[tid];
+        if (tid < 64) lnp[576 + tid] = a.w.b1[tid];
+    }
+    char* wmlp = smem_raw + sizeof(SM) + 640 * sizeof(float);       // [w1: 12 frags | w2: 12 frags]
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int f = wave * 3 + i3;
+        dma_frag(f < 12 ? reinterpret_cast<const char*>(w1) + f * 1024 : reinterpret_cast<const char*>(w2) + (f - 12) * 1024,
+                 wmlp + f * 1024);
+    }
+    wait_vm0();
+    __syncthreads();
+
+    // row-wise phases (LN1, residual + LN2): thread <-> (row tid / 8, 12 features)
+    const int2 sp_ln = tm.row_sp(tid >> 3);
+    // MLP phases: wave <-> (16-row tile tt, half of the output features)
+    const int tt = wave & 3, half = wave >> 2;
+    // lane offsets of the gathered W_v fragments (low / high half of each group of 8 channels)
+    int voff[2];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi) {
+        const int rs = 8 * (c >> 2) + (c & 3) + 4 * hi;   // 0..31
+        voff[hi] = ((rs >> 4) * 3) * 1024 + (g * 16 + (rs & 15)) * 16;   // K = 96 -> 3 fragments per 16 rows
+    }
+    int qlo[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) qlo[j] = ((j * 16 + c) / L) * L;
+
+    f32x4 xv[3];   // this thread's 12 row values of the tile to process (prefetched one tile ahead)
+    {
+        const long tok0 = tm.token_sp(blockIdx.x, sp_ln);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xv[i] = tok0 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok0 * 96 + (tid & 7) * 12)[i] : zero4();
+    }
+
+    constexpr int NR = MSST_F2_RING;   // pairs in flight: a pair is requested NR * 8 MFMAs of this wave before its use
+    frag ring[NR][2];
+#pragma unroll
+    for (int pi = 0; pi < NR; ++pi) load_pair(pi, ring[pi], wqkv, wout, H, h, voff);
+
+#ifdef MSST_STAMPS
+    const bool stamp_on = (a.dbg & 8) && blockIdx.x == 100 && tid == MSST_F2_STAMP_TID;
+#endif
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        STAMP(0);
+        int t1 = threadIdx.x;
+        asm volatile("" : "+v"(t1));
+        const int lr = t1 >> 3, part = t1 & 7;
+        // ---------------- LN1 -> xn ----------------
+        {
+            float v[12];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s += v[i];
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+            const float mean = s * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2); vs += __shfl_xor(vs, 4);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[part * 12 + 4*i+e] + lnp[96 + part * 12 + 4*i+e];
+                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 12 + 4 * i]) = f2bf4(n4);
+            }
+        }
+        lds_barrier();
+        // ================= head h, all in this wave's registers =================
+        // Weight fragments arrive through a ring of six fragment pairs (see load_pair): the pair consumed now was
+        // requested six pairs = 48 MFMAs of this wave ago.
+        frag qB[4][2], kA[4][2], vA[4][2];
+        {
+            frag xf[4][3];   // LN1(x) as operand fragments: [16-row tile][k-step]
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) xf[t][ks] = P::ld_kc(&sm.xn[t * 16][ks * 32], LDX);
+#pragma unroll
+            for (int st = 0; st < 6; ++st) {
+                STAMP(3 + st);
+                if (st < 4) {
+                    // q and k: C[i = channel][j = row]; channel tiles (2m, 2m+1) -> k-chunk m of the operand
+                    const int m = st & 1;
+                    f32x4 ca[4], cb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { ca[t] = zero4(); cb[t] = zero4(); }
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const int pi = 3 * st + ks;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
+                            cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_pair(pi + NR, ring[pi % NR], wqkv, wout, H, h, voff);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (st < 2) qB[t][m] = pack2(ca[t], cb[t]); else kA[t][m] = pack2(ca[t], cb[t]);
+                    }
+                } else {
+                    // v^T: C[i = row][j = gathered channel]; row tiles (2m, 2m+1) -> k-chunk m (keys)
+                    const int mm = st - 4;
+                    f32x4 cl[4], ch[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) { cl[t] = zero4(); ch[t] = zero4(); }
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        const int pi = 3 * st + ks;
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
+                            ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        load_pair(pi + NR, ring[pi % NR], wqkv, wout, H, h, voff);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    vA[2 * mm][0] = pack2(cl[0], cl[1]);     vA[2 * mm][1] = pack2(cl[2], cl[3]);
+                    vA[2 * mm + 1][0] = pack2(ch[0], ch[1]); vA[2 * mm + 1][1] = pack2(ch[2], ch[3]);
+                }
+            }
+        }
+        STAMP(9);
+        frag oB[4][2];
+#ifdef MSST_F2_NOATT      // timing study only (wrong results)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { oB[j][0] = qB[j][0]; oB[j][1] = kA[j][1]; }
+        if (a.scale == 123.f)
+#endif
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 s[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t] = P::mma(kA[t][0], qB[j][0], zero4());   // C[i = key][j = query]
+                s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
+            }
+            const int lo = qlo[j], hi = lo + L;
+            float mx = -INFINITY;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * 16 + 4 * g + r;
+                    const float v = (key >= lo && key < hi) ? s[t][r] * a.scale : -INFINITY;
+                    s[t][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = colgroup_max(mx);
+            float sum = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - mx); s[t][r] = e; sum += e; }
+            sum = colgroup_sum(sum);
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s[t] = s[t] * inv;
+                if (a.drop.thr)
+                    s[t] = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
+            }
+            const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
+            f32x4 o[4];
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd) {
+                o[dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
+                o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+            }
+            oB[j][0] = pack2(o[0], o[1]);                     // natural channel order 0..31 of the head
+            oB[j][1] = pack2(o[2], o[3]);                     // 32..63
+        }
+        // out-projection slice of this head: C[i = feature][j = row].  The 8 per-head partials meet in four fp32
+        // LDS tiles in a fixed order: waves 0-3 store, barrier, waves 4-7 add on top, barrier, rows add the four.
+        STAMP(10);
+        // residual rows of this tile again (L2 hits) and the next tile's rows: q / k / v registers are free now.
+        // Per-thread indices of the row-wise phases are re-derived from a laundered thread id so that none of them
+        // stays live (= gets spilled) across the register-hungry head phase.
+        int t2 = threadIdx.x;
+        asm volatile("" : "+v"(t2));
+        const int lr2 = t2 >> 3, part2 = t2 & 7;
+        const long tok2 = tm.token_sp(tile, tm.row_sp(lr2));
+        f32x4 xr[3];
+        {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xr[i] = tok2 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok2 * 96 + part2 * 12)[i] : zero4();
+            const int nt = tile + gridDim.x;
+            const long tokn = nt < a.ntiles ? tm.token_sp(nt, tm.row_sp(lr2)) : -1;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + part2 * 12)[i] : zero4();
+        }
+        if (wave < 4) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int pi = 18 + mt;
+                float* dst = &sm.pbuf[wave][mt * 16 + 4 * g][c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 cj = P::mma(ring[pi % NR][0], oB[j][0], zero4());
+                    cj = P::mma(ring[pi % NR][1], oB[j][1], cj);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * LDA + j * 16] = cj[r];
+                }
+                load_pair((pi + NR) % 24, ring[pi % NR], wqkv, wout, H, h, voff);   // wraps into the next tile's q pairs
+            }
+            STAMP(11);
+            lds_barrier();
+        } else {
+            f32x4 oc[6][4];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                const int pi = 18 + mt;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    oc[mt][j] = P::mma(ring[pi % NR][0], oB[j][0], zero4());
+                    oc[mt][j] = P::mma(ring[pi % NR][1], oB[j][1], oc[mt][j]);
+                }
+                load_pair((pi + NR) % 24, ring[pi % NR], wqkv, wout, H, h, voff);
+            }
+            lds_barrier();
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) {
+                float* dst = &sm.pbuf[wave - 4][mt * 16 + 4 * g][c];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * LDA + j * 16] += oc[mt][j][r];
+            }
+        }
+        STAMP(12);
+        lds_barrier();
+        STAMP(13);
+
+        // ---------------- residual, LN2 -> xn (row-wise threads) ----------------
+        {
+            float v[12];
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int m0 = part2 * 12 + 4 * i;
+                f32x4 o4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o4[r] = ((sm.pbuf[0][m0 + r][lr2] + sm.pbuf[1][m0 + r][lr2]) + (sm.pbuf[2][m0 + r][lr2] + sm.pbuf[3][m0 + r][lr2])) + lnp[192 + m0 + r];
+                if (a.drop.thr && tok2 >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok2 * 24 + (m0 >> 2)), o4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o4[r] += xr[i][r]; v[4*i+r] = o4[r]; s1 += o4[r]; sm.pbuf[0][m0 + r][lr2] = o4[r]; }
+                if (a.x1 && tok2 >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok2 * 96 + m0) = o4;
+            }
+            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
+            const float mean = s1 * (1.f / 96.f);
+            float vs = 0.f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
+            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2); vs += __shfl_xor(vs, 4);
+            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 n4;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[288 + part2 * 12 + 4*i+e] + lnp[384 + part2 * 12 + 4*i+e];
+                *reinterpret_cast<s16x4*>(&sm.xn[lr2][part2 * 12 + 4 * i]) = f2bf4(n4);
+            }
+        }
+        STAMP(14);
+        lds_barrier();
+        STAMP(15);
+        // ---------------- MLP: wave <-> (row tile tt, half of the outputs) ----------------
+        int l3 = threadIdx.x & 63;
+        asm volatile("" : "+v"(l3));
+        const int g3 = l3 >> 4, c3 = l3 & 15;
+        const long tok = tm.token_sp(tile, tm.row_sp(tt * 16 + c3));
+        {
+            f32x4 hh[2];
+            hh[0] = zero4(); hh[1] = zero4();
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                const frag xb = P::ld_kc(&sm.xn[tt * 16][ks * 32], LDX);
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+                    hh[jn] = P::mma(*reinterpret_cast<const frag*>(wmlp + ((2 * half + jn) * 3 + ks) * 1024 + l3 * 16), xb, hh[jn]);
+            }
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int n0 = (2 * half + jn) * 16 + 4 * g3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hh[jn][r] = gelu_fast(hh[jn][r] + lnp[576 + n0 + r]);
+                if (a.drop.thr && tok >= 0) hh[jn] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jn]);
+                P::st_nat(&sm.hb[tt * 16][(2 * half + jn) * 16], LDH, hh[jn]);
+            }
+        }
+        lds_barrier();
+        {
+            f32x4 yy[3];
+#pragma unroll
+            for (int jm = 0; jm < 3; ++jm) yy[jm] = zero4();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const frag hbf = P::ld_kc(&sm.hb[tt * 16][ks * 32], LDH);
+#pragma unroll
+                for (int jm = 0; jm < 3; ++jm)
+                    yy[jm] = P::mma(*reinterpret_cast<const frag*>(wmlp + (12 + (3 * half + jm) * 2 + ks) * 1024 + l3 * 16), hbf, yy[jm]);
+            }
+            if (tok >= 0) {
+#pragma unroll
+                for (int jm = 0; jm < 3; ++jm) {
+                    const int m0 = (3 * half + jm) * 16 + 4 * g3;
+                    f32x4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = yy[jm][r] + lnp[480 + m0 + r];
+                    if (a.drop.thr) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] += sm.pbuf[0][m0 + r][tt * 16 + c3];
+                    *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+                }
+            }
+        }
+        STAMP(16);
+        lds_barrier();   // xn / pbuf / hb are rewritten by the next tile
+        STAMP(17);
+    }
+}
+
+int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st) {
+    static bool attr_set = false;
+    const size_t smem = sizeof(Fwd2Smem) + 640 * sizeof(float) + 24 * 1024;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_hw_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ProfScope ps(K_BLOCK_FWD, st);
+    hipLaunchKernelGGL(block_fwd_hw_kernel, dim3(grid), dim3(512), smem, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst
