@@ -616,7 +616,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 for (int ks = 0; ks < NKD; ++ks) wdo[t][ks] = P::ld_w(woutT, 96, h * 64 + t * 16, ks * 32);
         }
         // ---------------- phase B: wave <-> 16 query rows ----------------
-        f32x4 pr[4];
+        f32x4 pr[4], pdr[4];   // raw / dropped probabilities (C layout [key][query])
         {
 #pragma unroll
             for (int t = 0; t < 4; ++t) pr[t] = zero4();
@@ -650,10 +650,12 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                 if (a.drop.thr) pd = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pd);
                 P::st_nat(&sm.p[wave * 16][t * 16], LDH, pd);  // p[query][key]
+                pdr[t] = pd;
             }
         }
         STAMP(5);
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (!BF) __builtin_amdgcn_wave_barrier();
+        f32x4 dor[4];   // bf16: dO^T of this wave's queries stays in registers for dP
         {
             // o = P v  (C[i = d][j = query]) and dO = Wout_h^T da (C[i = d][j = query])
             f32x4 o[4], dov[4];
@@ -664,11 +666,21 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
 #pragma unroll
                 for (int t = 0; t < 4; ++t) wd0[t] = P::ld_w(woutT, 96, h * 64 + t * 16, 0);
             }
-#pragma unroll P::UNROLL
-            for (int k0 = 0; k0 < 64; k0 += KS) {
-                const frag pb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
+            if constexpr (BF) {
+                // P stays in registers: C tiles (2m, 2m+1) of S^T packed = B operand of key chunk m (permuted key order)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);
+                for (int m = 0; m < 2; ++m) {
+                    const frag pb = PBF16::pack2(pdr[2 * m], pdr[2 * m + 1]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = P::mma(PBF16::ld_kc_perm(reinterpret_cast<const bf16_t*>(&sm.vt[t * 16][m * 32]), LDH), pb, o[t]);
+                }
+            } else {
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 64; k0 += KS) {
+                    const frag pb = P::ld_kc(&sm.p[wave * 16][k0], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) o[t] = P::mma(P::ld_kc(&sm.vt[t * 16][k0], LDH), pb, o[t]);
+                }
             }
             if constexpr (PF_WDO) {
 #pragma unroll
@@ -710,20 +722,30 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             for (int t = 0; t < 4; ++t) {
                 P::st_nat(&sm.o[wave * 16][t * 16], LDH, o[t]);      // o[query][d]
                 P::st_nat(&sm.dO[wave * 16][t * 16], LDH, dov[t]);   // dO[query][d]
+                dor[t] = dov[t];
             }
         }
         STAMP(6);
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (!BF) __builtin_amdgcn_wave_barrier();
         {
             // dP^T[key][query] = sum_d v[key][d] dO[query][d]: A = v (k-strided read of vt), B = dO rows
             f32x4 dp[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) dp[t] = zero4();
-#pragma unroll P::UNROLL
-            for (int k0 = 0; k0 < 64; k0 += KS) {
-                const frag db = P::ld_kc(&sm.dO[wave * 16][k0], LDH);
+            if constexpr (BF) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t) dp[t] = P::mma(P::ld_ks(&sm.vt[k0][t * 16], LDH), db, dp[t]);
+                for (int m = 0; m < 2; ++m) {
+                    const frag db = PBF16::pack2(dor[2 * m], dor[2 * m + 1]);   // channel chunk m, permuted order
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dp[t] = P::mma(PBF16::ld_ks_perm(reinterpret_cast<const bf16_t*>(&sm.vt[m * 32][t * 16]), LDH), db, dp[t]);
+                }
+            } else {
+#pragma unroll P::UNROLL
+                for (int k0 = 0; k0 < 64; k0 += KS) {
+                    const frag db = P::ld_kc(&sm.dO[wave * 16][k0], LDH);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dp[t] = P::mma(P::ld_ks(&sm.vt[k0][t * 16], LDH), db, dp[t]);
+                }
             }
             if (a.drop.thr) {
 #pragma unroll

@@ -137,6 +137,39 @@ struct PBF16 {
         r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
         return r;
     }
+    // ---- operands for an MFMA whose OTHER operand is pack2(C tile 2m, C tile 2m+1) of a previous MFMA ----
+    // Such a register-built operand holds, in lane (c, g), the contraction indices {4g..4g+3} and {16+4g..16+4g+3}
+    // of the 32-chunk (a permutation of the natural 8g..8g+7, harmless when both operands use it).
+    // k-contiguous LDS operand in that order: p -> element (row 0, first k of the chunk)
+    static __device__ __forceinline__ frag ld_kc_perm(const elem* p, int ld) {
+        const int l = lane_id();
+        const elem* q = p + (l & 15) * ld + 4 * (l >> 4);
+        const s16x4 lo = *reinterpret_cast<const s16x4*>(q);
+        const s16x4 hi = *reinterpret_cast<const s16x4*>(q + 16);
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    // k-strided LDS operand (element (row, k) at p[k*ld + row]) in that order
+    static __device__ __forceinline__ frag ld_ks_perm(const elem* p, int ld) {
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int l = lane_id();
+        const elem* q = p + (4 * (l >> 4) + ((l & 15) >> 2)) * ld + (l & 3) * 4;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(q + 16 * ld));
+        s16x8 r;
+        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        return r;
+    }
+    static __device__ __forceinline__ frag pack2(f32x4 lo, f32x4 hi) {
+        const s16x4 a = f2bf4(lo), b = f2bf4(hi);
+        s16x8 r;
+        r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+        r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+        return r;
+    }
     static __device__ __forceinline__ void st_nat(elem* p, int ld, f32x4 c) {
         const int l = lane_id();
         *reinterpret_cast<s16x4*>(p + (l & 15) * ld + 4 * (l >> 4)) = f2bf4(c);
