@@ -21,6 +21,12 @@
 #ifndef MSST_F2_STAMP_TID
 #define MSST_F2_STAMP_TID 0
 #endif
+#ifndef MSST_F2_PADX
+#define MSST_F2_PADX 16
+#endif
+#ifndef MSST_F2_PADH
+#define MSST_F2_PADH 8
+#endif
 #ifndef MSST_F2_RING
 #define MSST_F2_RING 4
 #endif
@@ -34,8 +40,8 @@ typedef bf16_t elem;
 typedef s16x8 frag;
 
 struct Fwd2Smem {
-    static constexpr int LDX = 96 + 8;    // bf16 rows of 96 (+16 B pad: conflict-free b128 fragment reads)
-    static constexpr int LDH = 64 + 8;
+    static constexpr int LDX = 96 + MSST_F2_PADX;   // bf16 rows of 96 + pad (row stride = 2 mod 4 sixteen-byte slots: conflict-free b128 fragment reads)
+    static constexpr int LDH = 64 + MSST_F2_PADH;
     static constexpr int LDA = 64 + 4;    // fp32 [feature][row]: lane (c, g) -> bank 16 g + c for the atomics
     elem xn[64][LDX];                     // LN1(x), later LN2(x1)
     float pbuf[4][96][LDA];               // out-projection partials of head pairs (h, h + 4); [0] later holds x1
