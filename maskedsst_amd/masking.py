@@ -62,10 +62,42 @@ class MaskGenerator:
         m = self._draw(batch_size * channel_tokens).reshape(batch_size, -1)
         return torch.from_numpy(m), torch.from_numpy(self._indices(m, batch_size, num_masked))
 
-    def get_batch_tube_masked(self, batch_size, channel_tokens, num_masked, device=None):
-        m = self._draw(batch_size)
-        m = np.repeat(m[:, None], channel_tokens, axis=1).reshape(batch_size, -1)
-        return torch.from_numpy(m), torch.from_numpy(self._indices(m, batch_size, num_masked))
+    def get_batch_tube_masked(self, batch_size, channel_tokens, num_masked, device=None, rows=None):
+        """Tube masking (:404-416): one spatial mask per sample, repeated over the spectral tokens.
+
+        Every row holds the same number of trues (R = channel_tokens * mask_count * scale^2), so the
+        reference's row-major nonzero list is known in closed form: row r contributes
+        ``c * HW + pos_r[j]`` for c-major, position-ascending order, at offsets [R r, R (r + 1)).  The
+        index rows are cut from that list without materialising the [B, T] bool matrix first, and
+        ``rows = (lo, hi)`` restricts both outputs to the local rows of a data-parallel rank while the
+        RNG is still advanced for the whole global batch (one permutation per sample, in order)."""
+        n = batch_size
+        sel = np.empty((n, self.mask_count), dtype=np.int64)
+        for i in range(n):
+            sel[i] = np.random.permutation(self.token_count)[: self.mask_count]
+        lo, hi = (0, n) if rows is None else rows
+        hw = self.input_size // self.model_patch_size
+        HW = hw * hw
+        # positions (row-major in the hw x hw grid) covered by each coarse cell
+        cell = np.arange(self.token_count)
+        cy, cx = cell // self.rand_size, cell % self.rand_size
+        dy, dx = np.meshgrid(np.arange(self.scale), np.arange(self.scale), indexing="ij")
+        table = ((cy[:, None, None] * self.scale + dy) * hw + (cx[:, None, None] * self.scale + dx)).reshape(self.token_count, -1)
+        per = table.shape[1] * self.mask_count                      # trues per spatial mask
+        R = per * channel_tokens                                    # trues per row of the [B, T] mask
+        if n * R < n * num_masked:
+            raise RuntimeError(f"shape mismatch: {n * R} masked entries for {n} x {num_masked} indices")
+        # index rows lo..hi-1 read list positions [num_masked lo, num_masked hi) -> source rows r0..r1-1
+        r0, r1 = (num_masked * lo) // R, -(-(num_masked * hi) // R)
+        need = np.arange(min(r0, lo), max(r1, hi))                 # rows whose positions are needed at all
+        pos = np.sort(table[sel[need]].reshape(need.shape[0], per), axis=1)
+        base = need[0]
+        cols = (np.arange(channel_tokens)[None, :, None] * HW + pos[r0 - base:r1 - base, None, :]).reshape(-1)
+        idx = cols[num_masked * lo - R * r0: num_masked * hi - R * r0].reshape(hi - lo, num_masked).astype(np.int64)
+        m = np.zeros((hi - lo, HW), dtype=bool)
+        m[np.arange(hi - lo)[:, None], pos[lo - base:hi - base]] = True
+        m = np.tile(m, (1, channel_tokens))
+        return torch.from_numpy(m), torch.from_numpy(idx)
 
 
 def topk_masks(batch, num_patches, num_masked):

@@ -84,8 +84,10 @@ class SimMIMSpatialSpectral(nn.Module):
         gb = batch * self.dp_world
         if self.mask_patch_size == 1:
             bm, idx = topk_masks(gb, T, num_masked)
-        elif self.tube_masking:
-            bm, idx = self.mask_generator.get_batch_tube_masked(gb, enc.num_spectral_patches, num_masked)
+        elif self.tube_masking:   # closed form: only the local rows are materialised (RNG still advances globally)
+            lo = self.dp_rank * batch
+            return self.mask_generator.get_batch_tube_masked(gb, enc.num_spectral_patches, num_masked,
+                                                             rows=(lo, lo + batch))
         else:
             bm, idx = self.mask_generator.get_batch(gb, enc.num_spectral_patches, num_masked)
         lo = self.dp_rank * batch
