@@ -38,3 +38,36 @@ def test_forward_stages(cfg, prec, tol):
     if prec == "fp32":
         mism = (out["dpred"].cpu() != sgn).float().mean().item()
         assert mism < 1e-3
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+@pytest.mark.parametrize("cfg", [dict(bands=50, depth=2, B=5), dict(bands=200, depth=1, B=3)],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_bf16_block_kernels_agree(cfg, dropout, monkeypatch):
+    """The three bf16 block-forward kernels (head-per-wave [default for 8 heads], tuned 4-wave, generic template)
+    compute the same math with the same dropout streams: outputs agree to bf16 rounding, and the default kernel
+    is bit-reproducible run to run (its head reduction has a fixed order)."""
+    model, params, x = build_product(dict(cfg, dropout=dropout), precision="bf16", device="cuda")
+    if dropout:
+        model.train()
+    eng = model.engine()
+    eng.prep_weights()
+    x0 = eng.tokenize(x.cuda(), None)
+    drop = (dropout, 1234) if dropout else (0.0, 0)
+
+    def run(dbg):
+        if dbg:
+            monkeypatch.setenv("MSST_DBG", str(dbg))
+        else:
+            monkeypatch.delenv("MSST_DBG", raising=False)
+        acts, x1s = eng.blocks_fwd(x0, save=True, drop=drop)
+        torch.cuda.synchronize()
+        return acts[-1].clone(), x1s[-1].clone()
+
+    y_hw, x1_hw = run(0)
+    y_hw2, _ = run(0)
+    assert torch.equal(y_hw, y_hw2)
+    y_t, x1_t = run(64)     # tuned 4-wave kernel
+    y_g, _ = run(16)        # generic template
+    assert relerr(y_hw, y_t) < 1e-2 and relerr(x1_hw, x1_t) < 1e-2
+    assert relerr(y_g, y_t) < 1e-2
