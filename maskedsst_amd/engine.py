@@ -47,7 +47,7 @@ class Engine:
         self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
         self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "256"))      # persistent grid of the row-wise bwd kernels
         self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "64"))  # x heads workgroups in the attention bwd
-        self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "16"))
+        self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "64"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self._wbuf = None
         self._jobs = None
