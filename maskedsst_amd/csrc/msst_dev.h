@@ -93,7 +93,10 @@ struct PBF16 {
     typedef bf16_t elem;
     typedef s16x8 frag;
     static constexpr int KS = 32;
-    static constexpr int UNROLL = 1;   // k-loops have 2-3 steps; full unrolling only inflates registers
+#ifndef MSST_BF_UNROLL
+#define MSST_BF_UNROLL 2
+#endif
+    static constexpr int UNROLL = MSST_BF_UNROLL;   // k-loops have 2-3 steps; full unrolling only inflates registers
     static constexpr int WAVES_PER_SIMD = 2;
     static constexpr int WAVES_BWD_ATTN = 2;  // 2 workgroups per CU (LDS 76 KB each)
     static constexpr int PADE = 8;  // 16 bytes
