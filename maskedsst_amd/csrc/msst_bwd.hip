@@ -617,6 +617,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         }
         // ---------------- phase B: wave <-> 16 query rows ----------------
         f32x4 pr[4], pdr[4];   // raw / dropped probabilities (C layout [key][query])
+        unsigned keep1 = 0;
         {
 #pragma unroll
             for (int t = 0; t < 4; ++t) pr[t] = zero4();
@@ -648,7 +649,11 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             for (int t = 0; t < 4; ++t) {
                 pr[t] = pr[t] * inv;
                 f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
-                if (a.drop.thr) pd = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pd);
+                if (a.drop.thr) {
+                    unsigned kb;
+                    pd = drop4_keep(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pd, kb);
+                    keep1 |= kb << (4 * t);   // the 16 keep decisions of this lane, reused for dP below
+                }
                 P::st_nat(&sm.p[wave * 16][t * 16], LDH, pd);  // p[query][key]
                 pdr[t] = pd;
             }
@@ -749,8 +754,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
             }
             if (a.drop.thr) {
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-                    dp[t] = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), dp[t]);
+                for (int t = 0; t < 4; ++t) dp[t] = drop4_bits(a.drop, keep1 >> (4 * t), dp[t]);
             }
             float delta = 0.f;
 #pragma unroll

@@ -268,19 +268,42 @@ struct Drop {
     float scale;
     int layer;            // block index (0 .. 2*depth-1)
 };
-__device__ __forceinline__ unsigned mix32(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
+// 64 mask bits (four 16-bit fields) of element group `group`: three 32-bit multiplies (the quarter-rate
+// instruction here) instead of the six of a double murmur finaliser; keep rates / field and neighbour correlations
+// checked in numpy over 4M groups (|corr| < 2e-3).
+__device__ __forceinline__ void drop_bits(const Drop& d, int site, unsigned group, unsigned& a, unsigned& b) {
+    unsigned x = group ^ (d.seed ^ ((unsigned)(d.layer * 4 + site) * 0x9E3779B9U));
+    x *= 0x9E3779B1U; x ^= x >> 15;
+    x *= 0x85EBCA6BU; x ^= x >> 13;
+    a = x;
+    b = x * 0xC2B2AE35U; b ^= b >> 16;
 }
 // site: 1 = attention probabilities, 2 = to_out, 3 = MLP hidden, 4 = MLP out
 __device__ __forceinline__ f32x4 drop4(const Drop& d, int site, unsigned group, f32x4 v) {
-    const unsigned a = mix32((d.seed ^ ((unsigned)(d.layer * 4 + site) * 0x9E3779B9U)) ^ mix32(group));
-    const unsigned b = mix32(a + 0x85ebca6bU);
+    unsigned a, b;
+    drop_bits(d, site, group, a, b);
     f32x4 r;
     r[0] = (a & 0xffffU) >= d.thr ? v[0] * d.scale : 0.f;
     r[1] = (a >> 16) >= d.thr ? v[1] * d.scale : 0.f;
     r[2] = (b & 0xffffU) >= d.thr ? v[2] * d.scale : 0.f;
     r[3] = (b >> 16) >= d.thr ? v[3] * d.scale : 0.f;
+    return r;
+}
+// same, also returning the four keep decisions as bits 0..3 (the attention backward reuses them for dP)
+__device__ __forceinline__ f32x4 drop4_keep(const Drop& d, int site, unsigned group, f32x4 v, unsigned& keep) {
+    unsigned a, b;
+    drop_bits(d, site, group, a, b);
+    const bool k0 = (a & 0xffffU) >= d.thr, k1 = (a >> 16) >= d.thr, k2 = (b & 0xffffU) >= d.thr, k3 = (b >> 16) >= d.thr;
+    keep = (unsigned)k0 | ((unsigned)k1 << 1) | ((unsigned)k2 << 2) | ((unsigned)k3 << 3);
+    f32x4 r;
+    r[0] = k0 ? v[0] * d.scale : 0.f; r[1] = k1 ? v[1] * d.scale : 0.f;
+    r[2] = k2 ? v[2] * d.scale : 0.f; r[3] = k3 ? v[3] * d.scale : 0.f;
+    return r;
+}
+__device__ __forceinline__ f32x4 drop4_bits(const Drop& d, unsigned keep, f32x4 v) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (keep >> i) & 1u ? v[i] * d.scale : 0.f;
     return r;
 }
 

@@ -1,16 +1,18 @@
 """numpy restatement of the kernels' stateless dropout masks (maskedsst_amd/csrc/msst_dev.h: Drop /
-mix32 / drop4) so that tests can hand the CPU oracle exactly the masks the HIP kernels use."""
+drop_bits / drop4) so that tests can hand the CPU oracle exactly the masks the HIP kernels use."""
 import numpy as np
 import torch
 
 
-def mix32(x):
-    x = x.astype(np.uint32)
+def drop_bits(key, group):
+    """msst_dev.h drop_bits: two 32-bit words = four 16-bit fields per element group"""
     with np.errstate(over="ignore"):
-        x ^= x >> np.uint32(16); x = x * np.uint32(0x7feb352d)
-        x ^= x >> np.uint32(15); x = x * np.uint32(0x846ca68b)
-        x ^= x >> np.uint32(16)
-    return x.astype(np.uint32)
+        x = (group.astype(np.uint32) ^ key).astype(np.uint32)
+        x = (x * np.uint32(0x9E3779B1)).astype(np.uint32); x ^= x >> np.uint32(15)
+        x = (x * np.uint32(0x85EBCA6B)).astype(np.uint32); x ^= x >> np.uint32(13)
+        a = x.copy()
+        b = (x * np.uint32(0xC2B2AE35)).astype(np.uint32); b ^= b >> np.uint32(16)
+    return a, b
 
 
 def keep_scaled(p, seed, layer, site, group, elem):
@@ -18,10 +20,8 @@ def keep_scaled(p, seed, layer, site, group, elem):
     0 or 1/(1-p') where p' = round(p*65536)/65536"""
     thr = np.uint32(int(p * 65536.0 + 0.5))
     scale = np.float32(1.0 / (1.0 - float(thr) / 65536.0))
-    with np.errstate(over="ignore"):
-        key = np.uint32(seed) ^ np.uint32((np.uint64(layer * 4 + site) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF))
-        a = mix32(key ^ mix32(group.astype(np.uint32)))
-        b = mix32(a + np.uint32(0x85ebca6b))
+    key = np.uint32(seed) ^ np.uint32((np.uint64(layer * 4 + site) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF))
+    a, b = drop_bits(key, group)
     bits = np.where(elem == 0, a & np.uint32(0xffff), np.where(elem == 1, a >> np.uint32(16),
                     np.where(elem == 2, b & np.uint32(0xffff), b >> np.uint32(16))))
     return np.where(bits >= thr, scale, np.float32(0.0)).astype(np.float32)
