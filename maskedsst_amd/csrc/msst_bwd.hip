@@ -953,7 +953,32 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
             for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
 #pragma unroll
             for (int i = 0; i < 24; ++i) dn[i] = 0.f;
-            for (int h = 0; h < a.H; ++h) {
+            // per-head partials: four heads' rows are requested together (one memory round trip per four heads,
+            // not one per head), summed in head order
+            const f32x4* d1 = reinterpret_cast<const f32x4*>(a.dx1 + tok * 96 + part * 24);
+            f32x4 d1v[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) d1v[i] = d1[i];
+            constexpr int VPH = 24 * (int)sizeof(E) / 16;   // 16-byte vectors per head row slice (3 bf16 / 6 fp32)
+            int h = 0;
+            for (; h + 4 <= a.H; h += 4) {
+                f32x4 raw[4][VPH];
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const f32x4* p = reinterpret_cast<const f32x4*>(parts + ((long)(h + hh) * a.ntok + tok) * 96 + part * 24);
+#pragma unroll
+                    for (int q = 0; q < VPH; ++q) raw[hh][q] = p[q];
+                }
+#pragma unroll
+                for (int hh = 0; hh < 4; ++hh) {
+                    const E* e = reinterpret_cast<const E*>(&raw[hh][0]);
+#pragma unroll
+                    for (int i = 0; i < 24; ++i) {
+                        if constexpr (sizeof(E) == 4) dn[i] += e[i]; else dn[i] += bf2f(e[i]);
+                    }
+                }
+            }
+            for (; h < a.H; ++h) {
                 const E* p = parts + ((long)h * a.ntok + tok) * 96 + part * 24;
 #pragma unroll
                 for (int i = 0; i < 24; ++i) {
@@ -984,11 +1009,10 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
             g1 += __shfl_xor(g1, 1); g1 += __shfl_xor(g1, 2);
             g2 += __shfl_xor(g2, 1); g2 += __shfl_xor(g2, 2);
             g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
-            const f32x4* d1 = reinterpret_cast<const f32x4*>(a.dx1 + tok * 96 + part * 24);
             f32x4* dst = reinterpret_cast<f32x4*>(a.dx + tok * 96 + part * 24);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                f32x4 t4 = d1[i], o4;
+                f32x4 t4 = d1v[i], o4;
                 f32x4 tm4 = t4;
                 if (a.drop.thr) tm4 = drop4(a.drop, 2, (unsigned)(tok * 24 + part * 6 + i), tm4);   // site 2 backward
 #pragma unroll
