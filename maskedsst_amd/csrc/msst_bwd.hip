@@ -933,71 +933,77 @@ template __global__ void block_bwd_attn_kernel<PBF16>(AttnBwdArgs);
 
 // ==========================================================================================
 // LN1 backward + residual:  dx = dx1 + LN1_bwd(sum_h part[h]; x)   (vit_spatial_spectral.py:22-29,:102)
-// persistent grid over 64-token tiles; 4 threads per row, 24 features each.
+// persistent grid over row tiles; 8 threads x 12 features per row (bf16 mode) or 4 x 24 (fp32 mode).
 // ==========================================================================================
 template <class E>
 __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
-    __shared__ float red[64][97];
-    const int tid = threadIdx.x, r = tid >> 2, part = tid & 3;
+    // features per thread: 12 in bf16 mode (8 threads per row, 32 rows per pass: half the registers, twice the waves
+    // and bytes in flight of the 24-feature mapping -- this kernel only moves data), 24 in the fp32 parity mode
+    constexpr int FPT = sizeof(E) == 2 ? 12 : 24, TPR = 96 / FPT, ROWS = 256 / TPR, NV = FPT / 4;
+    __shared__ float red[ROWS][97];
+    const int tid = threadIdx.x, r = tid / TPR, part = tid % TPR;
     const E* parts = reinterpret_cast<const E*>(a.dxn_part);
-    float dg[24], db[24], dbo[24], gam[24];
+    float dg[FPT], db[FPT], dbo[FPT], gam[FPT];
 #pragma unroll
-    for (int i = 0; i < 24; ++i) { dg[i] = 0.f; db[i] = 0.f; dbo[i] = 0.f; gam[i] = a.ln1_g[part * 24 + i]; }
-    const int ntiles = (a.ntok + 63) / 64;
+    for (int i = 0; i < FPT; ++i) { dg[i] = 0.f; db[i] = 0.f; dbo[i] = 0.f; gam[i] = a.ln1_g[part * FPT + i]; }
+    const int ntiles = (a.ntok + ROWS - 1) / ROWS;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long tok = (long)tile * 64 + r;
-        if (tok < a.ntok) {   // the 4 threads of a row are in/out together
-            float v[24], dn[24];
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * 24);
+        const long tok = (long)tile * ROWS + r;
+        if (tok < a.ntok) {   // the threads of a row are in/out together
+            float v[FPT], dn[FPT];
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + tok * 96 + part * FPT);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
+            for (int i = 0; i < NV; ++i) { f32x4 t4 = src[i]; v[4*i] = t4[0]; v[4*i+1] = t4[1]; v[4*i+2] = t4[2]; v[4*i+3] = t4[3]; }
 #pragma unroll
-            for (int i = 0; i < 24; ++i) dn[i] = 0.f;
-            // per-head partials: four heads' rows are requested together (one memory round trip per four heads,
-            // not one per head), summed in head order
-            const f32x4* d1 = reinterpret_cast<const f32x4*>(a.dx1 + tok * 96 + part * 24);
-            f32x4 d1v[6];
+            for (int i = 0; i < FPT; ++i) dn[i] = 0.f;
+            // per-head partials: four heads' row slices are requested together (one memory round trip per four
+            // heads, not one per head), summed in head order
+            const f32x4* d1 = reinterpret_cast<const f32x4*>(a.dx1 + tok * 96 + part * FPT);
+            f32x4 d1v[NV];
 #pragma unroll
-            for (int i = 0; i < 6; ++i) d1v[i] = d1[i];
-            constexpr int VPH = 24 * (int)sizeof(E) / 16;   // 16-byte vectors per head row slice (3 bf16 / 6 fp32)
+            for (int i = 0; i < NV; ++i) d1v[i] = d1[i];
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            constexpr int V8 = FPT * (int)sizeof(E) / 8;    // 8-byte vectors per head row slice
             int h = 0;
             for (; h + 4 <= a.H; h += 4) {
-                f32x4 raw[4][VPH];
+                f32x2 raw[4][V8];
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {
-                    const f32x4* p = reinterpret_cast<const f32x4*>(parts + ((long)(h + hh) * a.ntok + tok) * 96 + part * 24);
+                    const f32x2* p = reinterpret_cast<const f32x2*>(parts + ((long)(h + hh) * a.ntok + tok) * 96 + part * FPT);
 #pragma unroll
-                    for (int q = 0; q < VPH; ++q) raw[hh][q] = p[q];
+                    for (int q = 0; q < V8; ++q) raw[hh][q] = p[q];
                 }
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {
                     const E* e = reinterpret_cast<const E*>(&raw[hh][0]);
 #pragma unroll
-                    for (int i = 0; i < 24; ++i) {
+                    for (int i = 0; i < FPT; ++i) {
                         if constexpr (sizeof(E) == 4) dn[i] += e[i]; else dn[i] += bf2f(e[i]);
                     }
                 }
             }
             for (; h < a.H; ++h) {
-                const E* p = parts + ((long)h * a.ntok + tok) * 96 + part * 24;
+                const E* p = parts + ((long)h * a.ntok + tok) * 96 + part * FPT;
 #pragma unroll
-                for (int i = 0; i < 24; ++i) {
+                for (int i = 0; i < FPT; ++i) {
                     if constexpr (sizeof(E) == 4) dn[i] += p[i]; else dn[i] += bf2f(p[i]);
                 }
             }
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 24; ++i) s += v[i];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2);
+            for (int i = 0; i < FPT; ++i) s += v[i];
+#pragma unroll
+            for (int m = 1; m < TPR; m <<= 1) s += __shfl_xor(s, m);
             const float mean = s * (1.f / 96.f);
             float vs = 0.f;
 #pragma unroll
-            for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
-            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2);
+            for (int i = 0; i < FPT; ++i) { const float d = v[i] - mean; vs += d * d; }
+#pragma unroll
+            for (int m = 1; m < TPR; m <<= 1) vs += __shfl_xor(vs, m);
             const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
             float g1 = 0.f, g2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 24; ++i) {
+            for (int i = 0; i < FPT; ++i) {
                 const float xh = (v[i] - mean) * rstd;
                 v[i] = xh;
                 dg[i] += dn[i] * xh;
@@ -1006,15 +1012,15 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
                 g1 += dn[i];
                 g2 += dn[i] * xh;
             }
-            g1 += __shfl_xor(g1, 1); g1 += __shfl_xor(g1, 2);
-            g2 += __shfl_xor(g2, 1); g2 += __shfl_xor(g2, 2);
-            g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
-            f32x4* dst = reinterpret_cast<f32x4*>(a.dx + tok * 96 + part * 24);
 #pragma unroll
-            for (int i = 0; i < 6; ++i) {
+            for (int m = 1; m < TPR; m <<= 1) { g1 += __shfl_xor(g1, m); g2 += __shfl_xor(g2, m); }
+            g1 *= (1.f / 96.f); g2 *= (1.f / 96.f);
+            f32x4* dst = reinterpret_cast<f32x4*>(a.dx + tok * 96 + part * FPT);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
                 f32x4 t4 = d1v[i], o4;
                 f32x4 tm4 = t4;
-                if (a.drop.thr) tm4 = drop4(a.drop, 2, (unsigned)(tok * 24 + part * 6 + i), tm4);   // site 2 backward
+                if (a.drop.thr) tm4 = drop4(a.drop, 2, (unsigned)(tok * 24 + part * NV + i), tm4);   // site 2 backward
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o4[e] = t4[e] + rstd * (dn[4*i+e] - g1 - v[4*i+e] * g2);
@@ -1024,16 +1030,16 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
             }
         }
     }
-    // reduce dgamma / dbeta / d(to_out bias) over the 64 row-threads
+    // reduce dgamma / dbeta / d(to_out bias) over the row-threads
     float* slab = a.slab + (long)blockIdx.x * 288;
     for (int which = 0; which < 3; ++which) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 24; ++i) red[r][part * 24 + i] = which == 0 ? dg[i] : which == 1 ? db[i] : dbo[i];
+        for (int i = 0; i < FPT; ++i) red[r][part * FPT + i] = which == 0 ? dg[i] : which == 1 ? db[i] : dbo[i];
         __syncthreads();
         if (tid < 96) {
             float s = 0.f;
-            for (int rr = 0; rr < 64; ++rr) s += red[rr][tid];
+            for (int rr = 0; rr < ROWS; ++rr) s += red[rr][tid];
             slab[which * 96 + tid] = s;
         }
     }
