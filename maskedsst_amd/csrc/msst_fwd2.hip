@@ -12,11 +12,13 @@
 //     for the out-projection the rows of W_v are gathered so that O comes out in natural order.
 //   * no barrier and no LDS round trip between LN1 and the end of the out-projection (the tuned
 //     4-wave kernel has two barriers and five LDS round trips per head);
-//   * the 8 per-head out-projection partials meet in four fp32 LDS tiles in a fixed order (waves 0-3
-//     store, waves 4-7 add on top, the row-wise epilogue adds the four) -- ds_add_f32 was measured at
-//     ~160 cycles per instruction on gfx950 and is not used.
+//   * the 8 per-head out-projection partials meet in four fp32 LDS tiles in a fixed order (wave h and
+//     wave h + 4 share a tile: each stores half of the rows, then adds its other half on top of the
+//     partner's; the row-wise epilogue adds the four tiles) -- ds_add_f32 was measured at ~160 cycles per
+//     instruction on gfx950 and is not used.
 #include "msst_dev.h"
 #include "msst_kernels.h"
+#include <type_traits>
 
 #ifndef MSST_F2_STAMP_TID
 #define MSST_F2_STAMP_TID 0
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
         for (int i = 0; i < 3; ++i) xv[i] = tok0 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok0 * 96 + (tid & 7) * 12)[i] : zero4();
     }
 
-    constexpr int NR = MSST_F2_RING;   // pairs in flight: a pair is requested NR * 8 MFMAs of this wave before its use
+    constexpr int NR = MSST_F2_RING;
+    static_assert(NR == 4, "the out-projection / next-tile hand-over below assumes a ring of four pairs");   // pairs in flight: a pair is requested NR * 8 MFMAs of this wave before its use
     frag ring[NR][2];
 #pragma unroll
     for (int pi = 0; pi < NR; ++pi) load_pair(pi, ring[pi], wqkv, wout, H, h, voff);
@@ -239,6 +242,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             }
         }
         STAMP(9);
+        frag wx[2][2];   // out-projection pairs 22, 23 (18..21 are in the ring): requested now, used after the attention
+        load_pair(22, wx[0], wqkv, wout, H, h, voff);
+        load_pair(23, wx[1], wqkv, wout, H, h, voff);
         frag oB[4][2];
 #ifdef MSST_F2_NOATT      // timing study only (wrong results)
 #pragma unroll
@@ -288,8 +294,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             oB[j][0] = pack2(o[0], o[1]);                     // natural channel order 0..31 of the head
             oB[j][1] = pack2(o[2], o[3]);                     // 32..63
         }
-        // out-projection slice of this head: C[i = feature][j = row].  The 8 per-head partials meet in four fp32
-        // LDS tiles in a fixed order: waves 0-3 store, barrier, waves 4-7 add on top, barrier, rows add the four.
+        // out-projection slice of this head: C[i = feature][j = row]; the 8 per-head partials meet in four fp32 LDS tiles
         STAMP(10);
         // residual rows of this tile again (L2 hits) and the next tile's rows: q / k / v registers are free now.
         // Per-thread indices of the row-wise phases are re-derived from a laundered thread id so that none of them
@@ -307,44 +312,40 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + part2 * 12)[i] : zero4();
         }
-        if (wave < 4) {
+        // Each wave stores the tiles of its "own" 32 rows (waves 0-3: rows 0-31, waves 4-7: rows 32-63) and holds
+        // the other 32 rows in registers; after the barrier it adds the held half on top of what its partner
+        // (wave +- 4, same buffer) stored.  Fixed order, no idle half, 48 stores + 48 read-modify-writes per wave.
+        f32x4 hold[6][2];
+        auto outproj = [&](auto JW) {
+            constexpr int jw = decltype(JW)::value, jh = 2 - jw;
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
-                const int pi = 18 + mt;
-                float* dst = &sm.pbuf[wave][mt * 16 + 4 * g][c];
+                const frag wo0 = mt < 4 ? ring[(18 + mt) % NR][0] : wx[mt - 4][0];
+                const frag wo1 = mt < 4 ? ring[(18 + mt) % NR][1] : wx[mt - 4][1];
+                float* dst = &sm.pbuf[wave & 3][mt * 16 + 4 * g][c];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x4 cj = P::mma(ring[pi % NR][0], oB[j][0], zero4());
-                    cj = P::mma(ring[pi % NR][1], oB[j][1], cj);
+                for (int jj = 0; jj < 2; ++jj) {
+                    f32x4 cj = P::mma(wo0, oB[jw + jj][0], zero4());
+                    cj = P::mma(wo1, oB[jw + jj][1], cj);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[r * LDA + j * 16] = cj[r];
+                    for (int r = 0; r < 4; ++r) dst[r * LDA + (jw + jj) * 16] = cj[r];
+                    hold[mt][jj] = P::mma(wo0, oB[jh + jj][0], zero4());
+                    hold[mt][jj] = P::mma(wo1, oB[jh + jj][1], hold[mt][jj]);
                 }
-                load_pair((pi + NR) % 24, ring[pi % NR], wqkv, wout, H, h, voff);   // wraps into the next tile's q pairs
+                if (mt < 4) load_pair((18 + mt) % NR, ring[(18 + mt) % NR], wqkv, wout, H, h, voff);   // next tile's q pairs
             }
             STAMP(11);
             lds_barrier();
-        } else {
-            f32x4 oc[6][4];
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
-                const int pi = 18 + mt;
+                float* dst = &sm.pbuf[wave & 3][mt * 16 + 4 * g][c];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    oc[mt][j] = P::mma(ring[pi % NR][0], oB[j][0], zero4());
-                    oc[mt][j] = P::mma(ring[pi % NR][1], oB[j][1], oc[mt][j]);
-                }
-                load_pair((pi + NR) % 24, ring[pi % NR], wqkv, wout, H, h, voff);
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dst[r * LDA + (jh + jj) * 16] += hold[mt][jj][r];
             }
-            lds_barrier();
-#pragma unroll
-            for (int mt = 0; mt < 6; ++mt) {
-                float* dst = &sm.pbuf[wave - 4][mt * 16 + 4 * g][c];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[r * LDA + j * 16] += oc[mt][j][r];
-            }
-        }
+        };
+        if (wave < 4) outproj(std::integral_constant<int, 0>()); else outproj(std::integral_constant<int, 2>());
         STAMP(12);
         lds_barrier();
         STAMP(13);
