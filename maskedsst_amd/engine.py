@@ -299,6 +299,37 @@ class Engine:
             raise ValueError(f"dropout probability {p} outside (0, 1)")
         return p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
 
+    def _upload(self, dev, *arrays):
+        """Host arrays of one step -> device, without stalling the launch queue.
+
+        A ``.to(device)`` from pageable memory is stream ordered AND host blocking: the host sat until the
+        previous step had drained, and the GPU then idled while the next step's launches were issued (measured:
+        2 ms per 41 ms step).  Going through pinned staging buffers keeps the copies asynchronous: they queue on
+        the compute stream behind the previous step and the host keeps launching.  Two pinned sets alternate; a
+        set is rewritten only after the copy that last read it has run (host waits on its event, i.e. the host
+        runs at most two steps ahead)."""
+        if getattr(self, "_up", None) is None:
+            self._up = {"sets": [None, None], "k": 0}
+        up = self._up
+        k = up["k"]
+        up["k"] = 1 - k
+        cur = up["sets"][k]
+        sig = tuple((a.shape, a.dtype) for a in arrays)
+        if cur is None or cur["sig"] != sig:
+            cur = {"sig": sig,
+                   "pin": [torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True) for a in arrays],
+                   "dev": [torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, device=dev) for a in arrays],
+                   "ev": torch.cuda.Event()}
+            up["sets"][k] = cur
+        else:
+            cur["ev"].synchronize()
+        for pin, a in zip(cur["pin"], arrays):
+            pin.numpy()[...] = a
+        for d, pin in zip(cur["dev"], cur["pin"]):
+            d.copy_(pin, non_blocking=True)
+        cur["ev"].record(torch.cuda.current_stream(dev))
+        return cur["dev"]
+
     def simmim_loss(self, img, bool_mask, idx):
         """scalar loss attached to autograd (reference SimMIMSpatialSpectral.forward :203-340)"""
         self._require_cuda(img)
@@ -310,10 +341,7 @@ class Engine:
         bm = bool_mask.cpu().numpy() if torch.is_tensor(bool_mask) else np.asarray(bool_mask)
         ix = idx.cpu().numpy() if torch.is_tensor(idx) else np.asarray(idx)
         ptr, pos = inverse_csr(ix, T)
-        mask_u8 = torch.from_numpy(bm.astype(np.uint8)).to(dev, non_blocking=True)
-        idx32 = torch.from_numpy(ix.astype(np.int32)).to(dev, non_blocking=True)
-        csr_ptr = torch.from_numpy(ptr).to(dev, non_blocking=True)
-        csr_pos = torch.from_numpy(pos).to(dev, non_blocking=True)
+        mask_u8, idx32, csr_ptr, csr_pos = self._upload(dev, bm.astype(np.uint8), ix.astype(np.int32), ptr, pos)
         names = [n for n, _ in self.trainable()]
         params = [p for _, p in self.trainable()]
         if not torch.is_grad_enabled() or not any(p.requires_grad for p in params):
