@@ -115,8 +115,9 @@ def inverse_csr(idx, num_tokens):
     segments) instead of float atomics."""
     idx = np.asarray(idx)
     B, K = idx.shape
-    pos = np.argsort(idx, axis=1, kind="stable").astype(np.int32)
-    cnt = np.zeros((B, num_tokens + 1), dtype=np.int64)
-    np.add.at(cnt, (np.repeat(np.arange(B), K), idx.reshape(-1) + 1), 1)
+    key = idx.astype(np.uint16) if num_tokens < 65536 else idx     # 16-bit keys: numpy's stable sort is a radix sort
+    pos = np.argsort(key, axis=1, kind="stable").astype(np.int32)
+    flat = (np.arange(B, dtype=np.int64)[:, None] * (num_tokens + 1) + idx + 1).ravel()
+    cnt = np.bincount(flat, minlength=B * (num_tokens + 1)).reshape(B, num_tokens + 1)
     ptr = np.cumsum(cnt, axis=1).astype(np.int32)
     return ptr, pos
