@@ -1,12 +1,29 @@
-mkdir -p gpurun_out/prof2
+# round-end evidence: rocprofv3 kernel stats of the default bench command, the default bench line, PMC passes
+# (HBM traffic; SQ/LDS counters), other configurations.  Everything lands in gpurun_out/final/.
+OUT=gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/prof2 -o r1b -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-profile > gpurun_out/prof2/bench_under_rocprof.txt 2>&1
-rm -f gpurun_out/prof2/*kernel_trace.csv
-head -12 gpurun_out/prof2/r1b_kernel_stats.csv
-timeout 600 python bench.py > gpurun_out/bench_default.json 2>gpurun_out/bench_default.err
-tail -1 gpurun_out/bench_default.json | cut -c1-1500
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d gpurun_out/pmc_f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d gpurun_out/pmc_w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
-python3 tools/pmc_summary.py gpurun_out/pmc_f | grep -A1 "block_" 
-python3 tools/pmc_summary.py gpurun_out/pmc_w | grep -A1 "block_"
-find gpurun_out/pmc_f gpurun_out/pmc_w -name "*.csv" -size +1M -delete
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o r01 -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1
+find $OUT/stats -name "*kernel_trace.csv" -delete
+timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
+tail -1 $OUT/bench_default.json | cut -c1-600
+timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null
+for pass in "FETCH_SIZE" "WRITE_SIZE"; do
+  rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+done
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -f csv -d $OUT/pmc_sq1 -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_MFMA --kernel-trace -f csv -d $OUT/pmc_sq2 -- $B > /dev/null 2>&1
+python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE > $OUT/pmc_fetch.txt
+python3 tools/pmc_summary.py $OUT/pmc_WRITE_SIZE > $OUT/pmc_write.txt
+( python3 tools/pmc_summary.py $OUT/pmc_sq1; python3 tools/pmc_summary.py $OUT/pmc_sq2 ) > $OUT/pmc_sq.txt
+grep -A1 "block_" $OUT/pmc_fetch.txt; grep -A1 "block_" $OUT/pmc_write.txt
+find $OUT -name "*.csv" -size +512k -delete
+# other configurations (parity-test shapes and the batch sweep), one line each
+( python3 bench.py --no-cpu-baseline --dropout 0 | tail -1
+  python3 bench.py --no-cpu-baseline --bands 50 | tail -1
+  python3 bench.py --no-cpu-baseline --batch 64 | tail -1
+  python3 bench.py --no-cpu-baseline --batch 1024 --steps 5 | tail -1
+  python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null
+cut -c1-200 $OUT/bench_other_configs.jsonl
+ls -la $OUT $OUT/stats/* | head -30
