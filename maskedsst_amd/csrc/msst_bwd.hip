@@ -628,21 +628,48 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
                 for (int t = 0; t < 4; ++t) pr[t] = P::mma(P::ld_kc(&sm.k[t * 16][k0], LDH), qb, pr[t]);  // C[i = key][j = query]
             }
             float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + 4 * g + r;
-                    const float v = (key >= qlo && key < qhi) ? pr[t][r] * a.scale : -INFINITY;
-                    pr[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
-            mx = colgroup_max(mx);
             float sum = 0.f;
+            if constexpr (BF) {
+                // same arithmetic as block_fwd_hw_kernel: exp2(s c - max c), c = scale log2 e; nothing to mask when L == 64
+                const float cs = a.scale * 1.44269504088896340736f;
+                if (L == 64) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                    for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = P::exp(pr[t][r] - mx); pr[t][r] = e; sum += e; }
+                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = t * 16 + 4 * g + r;
+                            const float v = (key >= qlo && key < qhi) ? pr[t][r] : -INFINITY;
+                            pr[t][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
+                }
+                mx = colgroup_max(mx);
+                const float mc = mx * cs;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(pr[t][r], cs, -mc)); pr[t][r] = e; sum += e; }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * 16 + 4 * g + r;
+                        const float v = (key >= qlo && key < qhi) ? pr[t][r] * a.scale : -INFINITY;
+                        pr[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+                mx = colgroup_max(mx);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { const float e = P::exp(pr[t][r] - mx); pr[t][r] = e; sum += e; }
+            }
             sum = colgroup_sum(sum);
             const float inv = 1.f / sum;
 #pragma unroll

@@ -259,23 +259,34 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 s[t] = P::mma(kA[t][0], qB[j][0], zero4());   // C[i = key][j = query]
                 s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
             }
-            const int lo = qlo[j], hi = lo + L;
+            // softmax over the keys of the query's own sequence.  exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e:
+            // one FMA + one v_exp per element; with 64-token sequences (spatial blocks) nothing is masked
+            const float cs = a.scale * 1.44269504088896340736f;
             float mx = -INFINITY;
+            if (L == 64) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = t * 16 + 4 * g + r;
-                    const float v = (key >= lo && key < hi) ? s[t][r] * a.scale : -INFINITY;
-                    s[t][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+            } else {
+                const int lo = qlo[j], hi = lo + L;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = t * 16 + 4 * g + r;
+                        const float v = (key >= lo && key < hi) ? s[t][r] : -INFINITY;
+                        s[t][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            }
             mx = colgroup_max(mx);
+            const float mc = mx * cs;
             float sum = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __expf(s[t][r] - mx); s[t][r] = e; sum += e; }
+                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
             sum = colgroup_sum(sum);
             const float inv = 1.f / sum;
 #pragma unroll
