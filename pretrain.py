@@ -4,9 +4,10 @@ kernels.  Same config files / keys, same seeding, same loop shape (``model(img)`
 ``loss.backward()`` -> ``optimizer.step()``), same checkpoint dictionary.
 
 Differences from the reference script, all opt-in or forced by the environment:
-  * data: the GeoTIFF readers are out of scope -> ``--synthetic`` (default) draws standardised random
-    cubes shaped like ``EnMAPWorldCoverDataset`` tiles ([bands, 64, 64]) and takes the same random
-    8x8 crop (reference pretrain.py:99-107);
+  * data: the GeoTIFF readers are out of scope -> ``--synthetic`` (default) samples a pool of standardised
+    random tiles shaped like ``EnMAPWorldCoverDataset`` output ([bands, 64, 64]) and takes the same random
+    8x8 crop per batch (reference pretrain.py:99-107) through ``maskedsst_amd.data.SyntheticCubeLoader``
+    (worker thread, pinned staging, asynchronous host->device copies);
   * wandb is optional (absent here); losses are printed every ``logging_freq`` steps;
   * ``--dp``: one process per GPU under ``python -m torch.distributed.run`` (RCCL gradient all-reduce);
   * optimizer: fused AdamW over the flat parameter buffer (``--torch-optim`` keeps torch.optim.AdamW
@@ -23,6 +24,7 @@ import torch
 
 from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
 from maskedsst_amd.config import get_pretrain_config
+from maskedsst_amd.data import SyntheticCubeLoader
 from maskedsst_amd.optim import FusedAdamW, attach_data_parallel
 
 SEED = 5
@@ -34,6 +36,7 @@ def main():
     ap.add_argument("--general-config", default="configs/config.yaml")
     ap.add_argument("--synthetic", action="store_true", default=True)
     ap.add_argument("--tiles", type=int, default=256, help="synthetic 64x64 tiles per epoch")
+    ap.add_argument("--pool-tiles", type=int, default=64, help="distinct synthetic tiles held in host memory")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
@@ -95,7 +98,7 @@ def main():
     scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=5)
     reducer = attach_data_parallel(model) if world > 1 else None
 
-    # synthetic standardised tiles [tiles, bands, 64, 64] (per-band N(0,1), like StandardizeEnMAP output)
+    # synthetic standardised tiles [bands, 64, 64] (per-band N(0,1), like StandardizeEnMAP output), cropped per batch
     gen = torch.Generator().manual_seed(SEED + 1000 * rank)
     per_rank = config.batch_size // world
     steps_per_epoch = max(1, args.tiles // config.batch_size)
@@ -103,13 +106,9 @@ def main():
     step, losses, t0 = 0, [], time.time()
     for epoch in range(config.epoch):
         model.train()
-        for _ in range(steps_per_epoch):
-            tile = torch.randn(per_rank, config.n_bands, 64, 64, generator=gen)
-            if config.image_size != 64:
-                x, y = torch.randint(0, 64 - config.image_size, (2,))
-            else:
-                x, y = 0, 0
-            img = tile[:, :, x:x + config.image_size, y:y + config.image_size].contiguous().to(device, non_blocking=True)
+        loader = SyntheticCubeLoader(per_rank, config.n_bands, image_size=config.image_size, pool_tiles=args.pool_tiles,
+                                     steps=steps_per_epoch, seed=SEED + 1000 * rank + epoch, device=device)
+        for img in loader:
             optimizer.zero_grad()
             loss = model(img)
             loss.backward()
@@ -129,6 +128,7 @@ def main():
                           f"{step * config.batch_size / (time.time() - t0):.1f} samples/s", flush=True)
             if args.max_steps and step >= args.max_steps:
                 break
+        loader.close()
         if args.save_dir and rank == 0 and epoch % config.model_save_freq == 0:
             os.makedirs(args.save_dir, exist_ok=True)
             stats = {"losses": torch.stack(losses).cpu(), "config": config.__dict__,

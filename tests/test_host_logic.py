@@ -238,3 +238,22 @@ def test_load_checkpoint_semantics():
                               heads=2, mlp_dim=64, channels=30, spectral_pos_embed=True, spectral_pos=[0, 1, 2])
     with pytest.raises(RuntimeError):
         load_checkpoint(Cfg(), enc2, "mlp_head", "cpu", checkpoint=ckpt)
+
+
+def test_synthetic_cube_loader_contract():
+    """pretrain.py:99-107 contract: [B, bands, S, S] windows, one window position per batch, tiles drawn
+    from a fixed standardised pool; deterministic under the seed; trailing zero bands for Houston."""
+    from maskedsst_amd.data import SyntheticCubeLoader
+    ld = SyntheticCubeLoader(6, 50, image_size=8, pool_tiles=5, steps=4, seed=11, device="cpu", zero_pad_bands=2)
+    ref = SyntheticCubeLoader(6, 50, image_size=8, pool_tiles=5, steps=0, seed=11, device="cpu", zero_pad_bands=2)
+    n = 0
+    for img in ld:
+        idx, (x, y) = ref.draw()
+        assert 0 <= x < 56 and 0 <= y < 56
+        exp = ref.pool[idx][:, :, x:x + 8, y:y + 8]
+        assert img.shape == (6, 50, 8, 8) and img.dtype == torch.float32
+        assert np.array_equal(img.numpy(), exp)
+        assert float(img[:, 48:].abs().max()) == 0.0
+        n += 1
+    assert n == 4
+    assert abs(float(ref.pool[:, :48].std()) - 1.0) < 0.02
