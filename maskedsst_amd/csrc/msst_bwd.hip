@@ -65,24 +65,51 @@ __global__ __launch_bounds__(384) void head_bwd_kernel(HeadBwdArgs a) {
 
 // ==========================================================================================
 // reduce_segs: deterministic reduction of per-workgroup partial-gradient slabs, all segments of one
-// backward stage in ONE launch.  A 256-thread block owns 32 consecutive outputs of one segment:
-// 8 thread groups stride over the slabs, partials are combined through LDS in a fixed order.
+// backward stage in ONE launch.  A 256-thread block owns 32 (or, 16-byte path, 128) consecutive outputs of one
+// segment: 8 thread groups stride over the slabs, partials are combined through LDS in a fixed order.
 // ==========================================================================================
 __global__ __launch_bounds__(256) void reduce_segs_kernel(RSegs r) {
-    __shared__ float part[8][33];
+    __shared__ f32x4 part[8][33];
     int si = 0;
     while (si + 1 < r.nseg && (int)blockIdx.x >= r.s[si + 1].blk0) ++si;
     const RSeg g = r.s[si];
     const int io = threadIdx.x & 31, sg = threadIdx.x >> 5;
+    if (g.vec4) {
+        // 128 consecutive outputs per block, 4 per thread; the slab loop keeps four 16-byte requests in flight
+        const int i = (((int)blockIdx.x - g.blk0) * 32 + io) * 4;
+        f32x4 s = zero4();
+        if (i < g.n) {
+            const float* p = g.src + i;
+            int k = sg;
+            for (; k + 24 < g.nslab; k += 32) {
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long)k * g.slab_stride);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long)(k + 8) * g.slab_stride);
+                const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (long)(k + 16) * g.slab_stride);
+                const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (long)(k + 24) * g.slab_stride);
+                s = (((s + v0) + v1) + v2) + v3;
+            }
+            for (; k < g.nslab; k += 8) s = s + *reinterpret_cast<const f32x4*>(p + (long)k * g.slab_stride);
+        }
+        part[sg][io] = s;
+        __syncthreads();
+        if (sg == 0 && i < g.n) {
+            const f32x4 t = ((part[0][io] + part[1][io]) + (part[2][io] + part[3][io])) +
+                            ((part[4][io] + part[5][io]) + (part[6][io] + part[7][io]));
+            const int row = i / g.row_len, col = i - row * g.row_len;
+            *reinterpret_cast<f32x4*>(g.dst + (long)row * g.row_stride + col) = t;
+        }
+        return;
+    }
     const int i = ((int)blockIdx.x - g.blk0) * 32 + io;
     float s = 0.f;
     if (i < g.n)
         for (int k = sg; k < g.nslab; k += 8) s += g.src[(long)k * g.slab_stride + i];
-    part[sg][io] = s;
+    float* ps = reinterpret_cast<float*>(&part[0][0]);
+    ps[sg * 33 + io] = s;
     __syncthreads();
     if (sg == 0 && i < g.n) {
-        const float t = ((part[0][io] + part[1][io]) + (part[2][io] + part[3][io])) +
-                        ((part[4][io] + part[5][io]) + (part[6][io] + part[7][io]));
+        const float t = ((ps[0 * 33 + io] + ps[1 * 33 + io]) + (ps[2 * 33 + io] + ps[3 * 33 + io])) +
+                        ((ps[4 * 33 + io] + ps[5 * 33 + io]) + (ps[6 * 33 + io] + ps[7 * 33 + io]));
         const int row = i / g.row_len, col = i - row * g.row_len;
         g.dst[(long)row * g.row_stride + col] = t;
     }

@@ -140,7 +140,7 @@ int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st);
 struct RSeg {
     const float* src; float* dst;
     long slab_stride;
-    int nslab, n, row_len, row_stride, blk0, _pad;
+    int nslab, n, row_len, row_stride, blk0, vec4;
 };
 #define MSST_MAX_RSEG 72
 struct RSegs { RSeg s[MSST_MAX_RSEG]; int nseg; int nblocks; };
@@ -152,8 +152,12 @@ struct RSegBuilder {
         RSeg& g = r.s[r.nseg++];
         g.src = src; g.dst = dst; g.slab_stride = slab_stride; g.nslab = nslab; g.n = n;
         g.row_len = row_len > 0 ? row_len : n; g.row_stride = row_stride > 0 ? row_stride : n;
-        g.blk0 = r.nblocks; g._pad = 0;
-        r.nblocks += (n + 31) / 32;
+        g.blk0 = r.nblocks;
+        // 16-byte path: a thread owns 4 consecutive outputs (one dwordx4 per slab) when every address involved is aligned
+        g.vec4 = (n % 4 == 0 && g.row_len % 4 == 0 && g.row_stride % 4 == 0 && slab_stride % 4 == 0 &&
+                  ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) ? 1 : 0;
+        const int per_block = g.vec4 ? 128 : 32;
+        r.nblocks += (n + per_block - 1) / per_block;
         return true;
     }
 };
