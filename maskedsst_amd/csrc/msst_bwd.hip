@@ -41,15 +41,25 @@ __global__ __launch_bounds__(384) void head_bwd_kernel(HeadBwdArgs a) {
         }
         __syncthreads();
         if (tid < P) for (int n = 0; n < N; ++n) accB += gsh[n][tid];
-        for (int n = qg; n < N; n += 4) {
-            const long off = ((long)b * T + c * N + n) * 96 + d;
-            const float yv = a.y[off];
-            float dyv = 0.f;
+        for (int n0 = qg; n0 < N; n0 += 32) {   // eight rows requested together (was one memory round trip per row)
+            float yv[8];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) {
-                if (p < P) { const float gp = gsh[n][p]; dyv += gp * Wreg[p]; accW[p] += gp * yv; }
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + 4 * j;
+                yv[j] = n < N ? a.y[((long)b * T + c * N + n) * 96 + d] : 0.f;
             }
-            a.dy[off] = dyv;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int n = n0 + 4 * j;
+                if (n < N) {
+                    float dyv = 0.f;
+#pragma unroll
+                    for (int p = 0; p < 16; ++p) {
+                        if (p < P) { const float gp = gsh[n][p]; dyv += gp * Wreg[p]; accW[p] += gp * yv[j]; }
+                    }
+                    a.dy[((long)b * T + c * N + n) * 96 + d] = dyv;
+                }
+            }
         }
         __syncthreads();
     }
