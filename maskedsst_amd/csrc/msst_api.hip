@@ -84,6 +84,8 @@ static TileMap make_tilemap(int mode, int B, int S, int N) {
     TileMap tm;
     tm.mode = mode;
     tm.N = N;
+    tm.nshift = -1;
+    for (int sh = 0; sh < 31; ++sh) if ((1 << sh) == N) tm.nshift = sh;
     tm.T = S * N;
     tm.L = mode == MSST_MODE_SPATIAL ? N : S;
     tm.TS = 64 / tm.L;

@@ -465,7 +465,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
     constexpr int CPR = 96 * (int)sizeof(elem) / 16;   // 16-byte chunks per row (copy-out of the partial)
 
 #ifdef MSST_STAMPS
-    const bool stamp_on = (a.dbg & 8) && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0;
+    const bool stamp_wg = (a.dbg & 8) && blockIdx.x == 7 && blockIdx.y == 3 && tid == 0;
 #endif
     // bf16: software prefetch (global round trips are ~2k cycles under load); fp32 keeps the simple loads
     // (measured: prefetching rows + da + both weight sets needs ~400 registers -> 1 workgroup/CU, slower than
@@ -502,6 +502,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_ATTN) void block_bwd_attn_kernel(
         for (int i = 0; i < 6; ++i) xv[i] = tok0 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok0 * 96 + lpart * 24)[i] : zero4();
     }
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+#ifdef MSST_STAMPS
+        const bool stamp_on = stamp_wg && tile == blockIdx.x + 20 * (int)gridDim.x;   // a mid-walk tile (the last ones run on a half-empty chip)
+#endif
         STAMP(0);
         const long tok_ln = tm.token_sp(tile, sp_ln);
         f32x4 dav[6];         // da rows of this tile (consumed after phase A)
@@ -1342,13 +1345,15 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     dim3 grid(nchunk, a.H);
     if (prec == MSST_PREC_F32) {
-        const size_t smem = sizeof(AttnBwdSmem<PF32>) + 192 * sizeof(float);
+        const size_t smem = sizeof(AttnBwdSmem<PF32>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad
         int rc = set_smem(&block_bwd_attn_kernel<PF32>, smem, d0);
         if (rc) return rc;
         ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
+    } else if (!(a.dbg & 16)) {
+        return launch_block_bwd_attn_bf16(a, nchunk, st);   // MSST_DBG=16 selects the template kernel below (reference for the tuned one)
     } else {
-        const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float);
+        const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad
         int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);
         if (rc) return rc;
         ProfScope ps(K_BWD_ATTN, st);

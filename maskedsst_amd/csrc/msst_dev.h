@@ -72,6 +72,9 @@ struct PF32 {
         const int l = lane_id();
         return p[(l >> 4) * ld + (l & 15)];
     }
+    // (the bf16 policy has k-permuted variants of the LDS operand loads; in fp32 they are the plain ones)
+    static __device__ __forceinline__ frag ld_kc_perm(const elem* p, int ld) { return ld_kc(p, ld); }
+    static __device__ __forceinline__ frag ld_ks_perm(const elem* p, int ld) { return ld_ks(p, ld); }
     // global weight fragment: rows row0..+15, k-slice starting at k0 of a [R][K] matrix (fp32: row-major)
     static __device__ __forceinline__ frag ld_w(const elem* w, int K, int row0, int k0) {
         return ld_kc(w + (long)row0 * K + k0, K);
@@ -211,6 +214,31 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
     return v;
 }
 
+// sum over the 4 lanes of a quad (lanes l, l^1, l^2, l^3), result on every lane: two DPP quad_perm moves on the
+// VALU -- __shfl_xor compiles to ds_bpermute_b32, one LDS round trip per step
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+    return v;
+}
+
+// Software pipeline over N fully unrolled steps: the operands of step s are requested D steps before its MFMAs
+// (register slots are the caller's, indexed s % (D + 1)).  The scheduling fences pin the order: left alone, the
+// compiler sinks every LDS read next to its use (read / s_waitcnt lgkmcnt(0) / MFMA) once registers are tight.
+#define MSST_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <int N, int D, class Issue, class Exec>
+__device__ __forceinline__ void swpipe(Issue issue, Exec exec) {
+#pragma unroll
+    for (int s = 0; s < D && s < N; ++s) issue(s);
+#pragma unroll
+    for (int s = 0; s < N; ++s) {
+        if (s + D < N) issue(s + D);
+        MSST_SCHED_FENCE();
+        exec(s);
+        MSST_SCHED_FENCE();
+    }
+}
+
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 // d/dx gelu_erf
 __device__ __forceinline__ float gelu_erf_grad(float x) {
@@ -239,6 +267,12 @@ __device__ __forceinline__ void dma_frag_async(const void* gsrc_frag, void* lds_
     const char* src = reinterpret_cast<const char*>(gsrc_frag) + lane_id() * 16;
     const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst_frag;
     asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "memory", "m0");
+}
+// Same, wave-uniform fragment address in SGPRs + a 32-bit lane offset (lane * 16) in one VGPR shared by all copies:
+// no 64-bit address pair per fragment for the compiler to hoist out of the tile loop and spill.
+__device__ __forceinline__ void dma_frag_async_s(const void* gsrc_frag_uniform, void* lds_dst_frag, int lane_off) {
+    const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_dst_frag;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(dst), "v"(lane_off), "s"(gsrc_frag_uniform) : "memory", "m0");
 }
 // Pull the 128-byte line holding p towards this XCD's L2 without tying up a register: a 4-byte LDS-DMA into a
 // 256-byte scratch area nobody reads.  Counts in vmcnt like any load (in-order return), so place it where the
@@ -333,6 +367,7 @@ __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; retur
 // ------------------------------------------------------------------------------------------
 struct TileMap {
     int mode, L, TS, N, T, nseq;
+    int nshift;   // log2(N) when N is a power of two (spectral token index without an integer division), else -1
     // loop-invariant part of a row: (sequence slot s, position p); s < 0 marks a padding row
     __device__ __forceinline__ int2 row_sp(int r) const {
         const int s = r / L;
@@ -343,7 +378,7 @@ struct TileMap {
         const int q = tile * TS + sp.x;
         if (q >= nseq) return -1;
         if (mode == 0) return (long)q * N + sp.y;
-        const int b = q / N, n = q - b * N;
+        const int b = nshift >= 0 ? (q >> nshift) : q / N, n = q - b * N;
         return (long)b * T + (long)sp.y * N + n;
     }
     __device__ __forceinline__ long token(int tile, int r) const {

@@ -164,6 +164,7 @@ struct RSegBuilder {
 int launch_reduce_segs(const RSegs& r, hipStream_t st);
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st);
+int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st);   // msst_bwd2.hip (bf16 throughput kernel)
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st);
 int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st);
