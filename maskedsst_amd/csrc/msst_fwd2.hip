@@ -12,10 +12,14 @@
 //     for the out-projection the rows of W_v are gathered so that O comes out in natural order.
 //   * no barrier and no LDS round trip between LN1 and the end of the out-projection (the tuned
 //     4-wave kernel has two barriers and five LDS round trips per head);
-//   * the 8 per-head out-projection partials meet in four fp32 LDS tiles in a fixed order (wave h and
-//     wave h + 4 share a tile: each stores half of the rows, then adds its other half on top of the
-//     partner's; the row-wise epilogue adds the four tiles) -- ds_add_f32 was measured at ~160 cycles per
-//     instruction on gfx950 and is not used.
+//   * the heads meet in ONE bf16 tile O [64 rows][8 x 64 channels] in LDS; the out-projection is then a K = 512
+//     GEMM split over the 8 waves as (half of the features, pair of 16-row tiles, half of K): 48 MFMAs per wave,
+//     each weight fragment serves two row tiles.  The two K halves are combined by a single exchange of three
+//     fp32 C tiles per wave through a lane-linear buffer, after which wave (row tile, feature half) holds its
+//     48 features of 16 finished rows in registers: bias, dropout, residual, the LN2 statistics (combined with
+//     the other feature half through 2 floats per row) and the MLP residual never touch LDS.  (The first version
+//     summed eight fp32 per-head partials through LDS: 288 four-byte LDS operations per wave and a row-wise
+//     re-read -- 44 % of the tile time.)
 #include "msst_dev.h"
 #include "msst_kernels.h"
 #include <type_traits>
@@ -37,6 +41,13 @@ namespace msst {
 
 namespace {
 
+// sum over 8 consecutive lanes (a row of the row-wise LN1 phase), on every lane: quad DPP moves, then the other quad of
+// the 8 through row_half_mirror (all four lanes of a quad already agree)
+__device__ __forceinline__ float oct_sum(float v) {
+    v = quad_sum(v);
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+
 typedef PBF16 P;
 typedef bf16_t elem;
 typedef s16x8 frag;
@@ -44,9 +55,11 @@ typedef s16x8 frag;
 struct Fwd2Smem {
     static constexpr int LDX = 96 + MSST_F2_PADX;   // bf16 rows of 96 + pad (row stride = 2 mod 4 sixteen-byte slots: conflict-free b128 fragment reads)
     static constexpr int LDH = 64 + MSST_F2_PADH;
-    static constexpr int LDA = 64 + 4;    // fp32 [feature][row]: lane (c, g) -> bank 16 g + c for the atomics
+    static constexpr int LDO = 512 + 16;  // 66 slots = 2 mod 4
     elem xn[64][LDX];                     // LN1(x), later LN2(x1)
-    float pbuf[4][96][LDA];               // out-projection partials of head pairs (h, h + 4); [0] later holds x1
+    elem ob[64][LDO];                     // attention output of the 8 heads, [row][h * 64 + channel]
+    f32x4 xch[8][3][64];                  // K-half exchange: [receiving wave][C tile][lane]
+    float2 st[8][16];                     // LN2 partial statistics (mean, M2 over 48 features): [wave][row in tile]
     elem hb[64][LDH];                     // GELU(W1 .) of the MLP
 };
 
@@ -70,7 +83,6 @@ __device__ __forceinline__ frag ld_w_gather(const elem* w, int K, int row32, int
 // weight-fragment pair number pi of head h (compile-time constant after unrolling): the stream a wave consumes per tile is
 //   0..5 q   6..11 k   (pair = fragments of channel tiles 2m, 2m+1 at k-step ks; pi = 3 (2 which + m) + ks)
 //   12..17 gathered v  (pair = low / high channel halves of block mm at k-step ks; pi = 12 + 3 mm + ks)
-//   18..23 out-projection slice (pair = the two 32-channel chunks of feature tile mt = pi - 18)
 __device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wqkv, const elem* wout, int H, int h,
                                           const int (&voff)[2]) {
     if (pi < 12) {
@@ -78,14 +90,11 @@ __device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wq
         const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
         out[0] = P::ld_w(wqkv, 96, r0, ks * 32);
         out[1] = P::ld_w(wqkv, 96, r0 + 16, ks * 32);
-    } else if (pi < 18) {
+    } else {
         const int mm = (pi - 12) / 3, ks = (pi - 12) % 3;
         const int r32 = (2 * H + h) * 64 + mm * 32;
         out[0] = ld_w_gather(wqkv, 96, r32, ks * 32, voff[0]);
         out[1] = ld_w_gather(wqkv, 96, r32, ks * 32, voff[1]);
-    } else {
-        out[0] = P::ld_w(wout, H * 64, (pi - 18) * 16, h * 64);
-        out[1] = P::ld_w(wout, H * 64, (pi - 18) * 16, h * 64 + 32);
     }
 }
 
@@ -93,7 +102,7 @@ __device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wq
 
 __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
     typedef Fwd2Smem SM;
-    constexpr int LDX = SM::LDX, LDH = SM::LDH, LDA = SM::LDA;
+    constexpr int LDX = SM::LDX, LDH = SM::LDH, LDO = SM::LDO;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     SM& sm = *reinterpret_cast<SM*>(smem_raw);
 
@@ -125,8 +134,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 
     // row-wise phases (LN1, residual + LN2): thread <-> (row tid / 8, 12 features)
     const int2 sp_ln = tm.row_sp(tid >> 3);
-    // MLP phases: wave <-> (16-row tile tt, half of the output features)
-    const int tt = wave & 3, half = wave >> 2;
+    // out-projection: wave <-> (feature half mh, row-tile pair rh, K half kh); it ends up owning row tile tt = 2 rh + kh
+    // of feature half mh, and keeps that role through LN2 and the MLP
+    const int mh = wave & 1, rh = (wave >> 1) & 1, kh = wave >> 2;
+    const int tt = 2 * rh + kh, half = mh;
     // lane offsets of the gathered W_v fragments (low / high half of each group of 8 channels)
     int voff[2];
 #pragma unroll
@@ -164,16 +175,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             float v[12];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+            if (tm.token_sp(tile, tm.row_sp(lr)) < 0) {   // padding row: the prefetch read a clamped address, normalise zeros
+#pragma unroll
+                for (int i = 0; i < 12; ++i) v[i] = 0.f;
+            }
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) s += v[i];
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
-            const float mean = s * (1.f / 96.f);
+            const float mean = oct_sum(s) * (1.f / 96.f);
             float vs = 0.f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
-            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2); vs += __shfl_xor(vs, 4);
-            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+            const float rstd = rsqrtf(oct_sum(vs) * (1.f / 96.f) + 1e-5f);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 f32x4 n4;
@@ -211,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(pi + NR, ring[pi % NR], wqkv, wout, H, h, voff);
+                        load_pair(pi + NR < 18 ? pi + NR : pi % NR, ring[pi % NR], wqkv, wout, H, h, voff);   // >= 18: the next tile's pair pi % NR
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -233,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(pi + NR, ring[pi % NR], wqkv, wout, H, h, voff);
+                        load_pair(pi + NR < 18 ? pi + NR : pi % NR, ring[pi % NR], wqkv, wout, H, h, voff);   // >= 18: the next tile's pair pi % NR
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     vA[2 * mm][0] = pack2(cl[0], cl[1]);     vA[2 * mm][1] = pack2(cl[2], cl[3]);
@@ -242,15 +255,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             }
         }
         STAMP(9);
-        frag wx[2][2];   // out-projection pairs 22, 23 (18..21 are in the ring): requested now, used after the attention
-        load_pair(22, wx[0], wqkv, wout, H, h, voff);
-        load_pair(23, wx[1], wqkv, wout, H, h, voff);
-        frag oB[4][2];
-#ifdef MSST_F2_NOATT      // timing study only (wrong results)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { oB[j][0] = qB[j][0]; oB[j][1] = kA[j][1]; }
-        if (a.scale == 123.f)
-#endif
+        // ================= attention of head h for the four query tiles; O rows go to the shared bf16 tile =================
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 s[4];
@@ -302,104 +307,118 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 o[dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
                 o[dd] = P::mma(vA[dd][1], p1, o[dd]);
             }
-            oB[j][0] = pack2(o[0], o[1]);                     // natural channel order 0..31 of the head
-            oB[j][1] = pack2(o[2], o[3]);                     // 32..63
+            // pack2(o[2u], o[2u + 1]) holds, in lane (c, g), the natural channels 32 u + 8 g .. + 7 of query row 16 j + c:
+            // one 16-byte store per half
+            int l4 = threadIdx.x & 63;
+            asm volatile("" : "+v"(l4));
+            elem* orow = &sm.ob[j * 16 + (l4 & 15)][h * 64 + 8 * (l4 >> 4)];
+            *reinterpret_cast<frag*>(orow) = pack2(o[0], o[1]);
+            *reinterpret_cast<frag*>(orow + 32) = pack2(o[2], o[3]);
         }
-        // out-projection slice of this head: C[i = feature][j = row]; the 8 per-head partials meet in four fp32 LDS tiles
         STAMP(10);
-        // residual rows of this tile again (L2 hits) and the next tile's rows: q / k / v registers are free now.
-        // Per-thread indices of the row-wise phases are re-derived from a laundered thread id so that none of them
-        // stays live (= gets spilled) across the register-hungry head phase.
-        int t2 = threadIdx.x;
-        asm volatile("" : "+v"(t2));
-        const int lr2 = t2 >> 3, part2 = t2 & 7;
-        const long tok2 = tm.token_sp(tile, tm.row_sp(lr2));
+        // rows owned from here on: lane (c, g) of wave (tt, half) <-> row 16 tt + c, features 16 (3 half + i) + 4 g .. + 3.
+        // Residual values of this tile (L2 hits) and the next tile's rows for LN1 are requested now: q / k / v registers are
+        // free.  Per-thread indices are re-derived from a laundered lane id so that none stays live across the head phase.
+        int l3 = threadIdx.x & 63;
+        asm volatile("" : "+v"(l3));
+        const int g3 = l3 >> 4, c3 = l3 & 15;
+        const long tok = tm.token_sp(tile, tm.row_sp(tt * 16 + c3));
         f32x4 xr[3];
         {
+            const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 48 * half + 4 * g3;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xr[i] = tok2 >= 0 ? reinterpret_cast<const f32x4*>(a.x + tok2 * 96 + part2 * 12)[i] : zero4();
+            for (int i = 0; i < 3; ++i) xr[i] = *reinterpret_cast<const f32x4*>(xrow + 16 * i);
+            int t2 = threadIdx.x;
+            asm volatile("" : "+v"(t2));
             const int nt = tile + gridDim.x;
-            const long tokn = nt < a.ntiles ? tm.token_sp(nt, tm.row_sp(lr2)) : -1;
+            const long tokn = nt < a.ntiles ? tm.token_sp(nt, tm.row_sp(t2 >> 3)) : -1;
+            const float* xn_row = a.x + (tokn >= 0 ? tokn : 0) * 96 + (t2 & 7) * 12;
 #pragma unroll
-            for (int i = 0; i < 3; ++i) xv[i] = tokn >= 0 ? reinterpret_cast<const f32x4*>(a.x + tokn * 96 + part2 * 12)[i] : zero4();
+            for (int i = 0; i < 3; ++i) xv[i] = reinterpret_cast<const f32x4*>(xn_row)[i];
         }
-        // Each wave stores the tiles of its "own" 32 rows (waves 0-3: rows 0-31, waves 4-7: rows 32-63) and holds
-        // the other 32 rows in registers; after the barrier it adds the held half on top of what its partner
-        // (wave +- 4, same buffer) stored.  Fixed order, no idle half, 48 stores + 48 read-modify-writes per wave.
-        f32x4 hold[6][2];
-        auto outproj = [&](auto JW) {
-            constexpr int jw = decltype(JW)::value, jh = 2 - jw;
+        lds_barrier();   // O complete
+        STAMP(11);
+        // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------
+        f32x4 acc[2][3];   // [row tile 2 rh + jj][feature tile 3 mh + i]
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) {
-                const frag wo0 = mt < 4 ? ring[(18 + mt) % NR][0] : wx[mt - 4][0];
-                const frag wo1 = mt < 4 ? ring[(18 + mt) % NR][1] : wx[mt - 4][1];
-                float* dst = &sm.pbuf[wave & 3][mt * 16 + 4 * g][c];
+        for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    f32x4 cj = P::mma(wo0, oB[jw + jj][0], zero4());
-                    cj = P::mma(wo1, oB[jw + jj][1], cj);
+            for (int i = 0; i < 3; ++i) acc[jj][i] = zero4();
+        {
+            frag fo[3][2], fw[3][3];   // O row fragments / Wout fragments of a k-step, requested two k-steps ahead
+            swpipe<8, 2>(
+                [&](int s8) {
+                    const int k0 = (8 * kh + s8) * 32;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[r * LDA + (jw + jj) * 16] = cj[r];
-                    hold[mt][jj] = P::mma(wo0, oB[jh + jj][0], zero4());
-                    hold[mt][jj] = P::mma(wo1, oB[jh + jj][1], hold[mt][jj]);
-                }
-                if (mt < 4) load_pair((18 + mt) % NR, ring[(18 + mt) % NR], wqkv, wout, H, h, voff);   // next tile's q pairs
+                    for (int i = 0; i < 3; ++i) fw[s8 % 3][i] = P::ld_w(wout, inner, (3 * mh + i) * 16, k0);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) fo[s8 % 3][jj] = P::ld_kc(&sm.ob[(2 * rh + jj) * 16][k0], LDO);
+                },
+                [&](int s8) {
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc[jj][i] = P::mma(fw[s8 % 3][i], fo[s8 % 3][jj], acc[jj][i]);
+                });
+        }
+        // the other K half of the row tile this wave gives away goes to its owner (wave ^ 4), lane-linear
+        {
+            f32x4* dst = &sm.xch[wave ^ 4][0][l3];
+            if (kh == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dst[i * 64] = acc[1][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; ++i) dst[i * 64] = acc[0][i];
             }
-            STAMP(11);
-            lds_barrier();
-#pragma unroll
-            for (int mt = 0; mt < 6; ++mt) {
-                float* dst = &sm.pbuf[wave & 3][mt * 16 + 4 * g][c];
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dst[r * LDA + (jh + jj) * 16] += hold[mt][jj][r];
-            }
-        };
-        if (wave < 4) outproj(std::integral_constant<int, 0>()); else outproj(std::integral_constant<int, 2>());
+        }
         STAMP(12);
         lds_barrier();
         STAMP(13);
-
-        // ---------------- residual, LN2 -> xn (row-wise threads) ----------------
+        // ---------------- bias, dropout, residual -> x1;  LN2 -> xn  (all in registers) ----------------
+        f32x4 x1r[3];   // x1 of the owned rows / features: stays in registers until the end of the MLP
         {
-            float v[12];
             float s1 = 0.f;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int m0 = part2 * 12 + 4 * i;
-                f32x4 o4;
+                const int m0 = (3 * half + i) * 16 + 4 * g3;
+                f32x4 o4 = (kh == 0 ? acc[0][i] : acc[1][i]) + sm.xch[wave][i][l3];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    o4[r] = ((sm.pbuf[0][m0 + r][lr2] + sm.pbuf[1][m0 + r][lr2]) + (sm.pbuf[2][m0 + r][lr2] + sm.pbuf[3][m0 + r][lr2])) + lnp[192 + m0 + r];
-                if (a.drop.thr && tok2 >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok2 * 24 + (m0 >> 2)), o4);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { o4[r] += xr[i][r]; v[4*i+r] = o4[r]; s1 += o4[r]; sm.pbuf[0][m0 + r][lr2] = o4[r]; }
-                if (a.x1 && tok2 >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok2 * 96 + m0) = o4;
+                for (int r = 0; r < 4; ++r) o4[r] += lnp[192 + m0 + r];
+                if (a.drop.thr && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                o4 = o4 + xr[i];
+                x1r[i] = o4;
+                s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
+                if (a.x1 && tok >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
             }
-            s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2); s1 += __shfl_xor(s1, 4);
-            const float mean = s1 * (1.f / 96.f);
-            float vs = 0.f;
+            // statistics of the 48 owned features of row c3 (sum over the 4 lane groups), then combined with the other half
+            const float mean_w = colgroup_sum(s1) * (1.f / 48.f);
+            float m2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
-            vs += __shfl_xor(vs, 1); vs += __shfl_xor(vs, 2); vs += __shfl_xor(vs, 4);
-            const float rstd = rsqrtf(vs * (1.f / 96.f) + 1e-5f);
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = x1r[i][r] - mean_w; m2 += d * d; }
+            m2 = colgroup_sum(m2);
+            if (g3 == 0) sm.st[wave][c3] = make_float2(mean_w, m2);
+            lds_barrier();
+            const float2 other = sm.st[wave ^ 1][c3];
+            const float mean = 0.5f * (mean_w + other.x);
+            const float dm = mean_w - other.x;
+            const float var = (m2 + other.y + dm * dm * 24.f) * (1.f / 96.f);   // Chan's pairwise combination, n = 48 + 48
+            const float rstd = rsqrtf(var + 1e-5f);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
+                const int m0 = (3 * half + i) * 16 + 4 * g3;
                 f32x4 n4;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[288 + part2 * 12 + 4*i+e] + lnp[384 + part2 * 12 + 4*i+e];
-                *reinterpret_cast<s16x4*>(&sm.xn[lr2][part2 * 12 + 4 * i]) = f2bf4(n4);
+                for (int r = 0; r < 4; ++r) n4[r] = (x1r[i][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
+                *reinterpret_cast<s16x4*>(&sm.xn[tt * 16 + c3][m0]) = f2bf4(n4);
             }
         }
         STAMP(14);
         lds_barrier();
         STAMP(15);
         // ---------------- MLP: wave <-> (row tile tt, half of the outputs) ----------------
-        int l3 = threadIdx.x & 63;
-        asm volatile("" : "+v"(l3));
-        const int g3 = l3 >> 4, c3 = l3 & 15;
-        const long tok = tm.token_sp(tile, tm.row_sp(tt * 16 + c3));
         {
             f32x4 hh[2];
             hh[0] = zero4(); hh[1] = zero4();
@@ -439,14 +458,14 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o4[r] = yy[jm][r] + lnp[480 + m0 + r];
                     if (a.drop.thr) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) o4[r] += sm.pbuf[0][m0 + r][tt * 16 + c3];
+                    o4 = o4 + x1r[jm];
                     *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
                 }
             }
         }
         STAMP(16);
-        lds_barrier();   // xn / pbuf / hb are rewritten by the next tile
+        // no barrier at the end of the tile: the next LN1 writes xn, last read before the barrier that precedes the second
+        // MLP GEMM; ob / xch / st / hb are rewritten only after later barriers of the next tile
         STAMP(17);
     }
 }
