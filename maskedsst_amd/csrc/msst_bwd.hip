@@ -164,7 +164,9 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) { dgam[i][r] = 0.f; dbet[i][r] = 0.f; }
     }
-    float dbias = 0.f;  // tid < 96: db2[tid]; 96 <= tid < 160: db1[tid - 96]
+    // bias gradients are column sums over the rows of a tile: one more MFMA against a fragment of ones in the weight-grad
+    // k-loop (every column of the C tile then holds the sum).  db1: this wave's 16 hidden units; db2: feature tiles wave, wave + 4
+    f32x4 db1a = zero4(), db2a = zero4(), db2b = zero4();
 
     // tile-invariant small vectors in LDS: ln2_g | ln2_b | b1
     float* lnp = reinterpret_cast<float*>(smem_raw + sizeof(SM));
@@ -325,20 +327,16 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int k0 = 0; k0 < 64; k0 += KS) {
             const frag ah = P::ld_ks(&sm.dhp[k0][wave * 16], LDH);  // A[i = n][k = row]
             const frag bh = P::ld_ks(&sm.h[k0][wave * 16], LDH);    // B[j = n][k = row]
+            const frag one = P::ones();
+            db1a = P::mma(ah, one, db1a);                                          // C[i = n][j = *] = sum_row dhp[row][n]
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
+                const frag dyt = P::ld_ks(&sm.dy[k0][t * 16], LDX);
                 dW1[t] = P::mma(ah, P::ld_ks(&sm.xn2[k0][t * 16], LDX), dW1[t]);  // C[i = n][j = m]
-                dW2[t] = P::mma(P::ld_ks(&sm.dy[k0][t * 16], LDX), bh, dW2[t]);   // C[i = m][j = n]
+                dW2[t] = P::mma(dyt, bh, dW2[t]);                                  // C[i = m][j = n]
+                if (t == wave) db2a = P::mma(dyt, one, db2a);                      // C[i = m][j = *] = sum_row dy[row][m]
+                if (t == wave + 4) db2b = P::mma(dyt, one, db2b);
             }
-        }
-        if (tid < 96) {
-            float s = 0.f;
-            for (int r = 0; r < 64; ++r) s += P::up(sm.dy[r][tid]);
-            dbias += s;
-        } else if (tid < 160) {
-            float s = 0.f;
-            for (int r = 0; r < 64; ++r) s += P::up(sm.dhp[r][tid - 96]);
-            dbias += s;
         }
         lds_barrier();
     }
@@ -352,8 +350,14 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
             slab[(wave * 16 + 4 * g + r) * 96 + t * 16 + c] = dW1[t][r];          // dW1[n][m]
             slab[6144 + (t * 16 + 4 * g + r) * 64 + wave * 16 + c] = dW2[t][r];   // dW2[m][n]
         }
-    if (tid < 96) slab[12288 + 64 + tid] = dbias;           // db2
-    else if (tid < 160) slab[12288 + tid - 96] = dbias;     // db1
+    if (c == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            slab[12288 + wave * 16 + 4 * g + r] = db1a[r];                                   // db1
+            slab[12288 + 64 + wave * 16 + 4 * g + r] = db2a[r];                              // db2, feature tile wave
+            if (wave < 2) slab[12288 + 64 + (wave + 4) * 16 + 4 * g + r] = db2b[r];          // db2, feature tile wave + 4
+        }
+    }
     // LN2 gamma/beta: sum over the 16 rows of the wave, then over waves through LDS
     float* red = reinterpret_cast<float*>(smem_raw);  // [4 waves][2][96]
     __syncthreads();

@@ -56,6 +56,7 @@ struct PF32 {
     static constexpr int PADE = 4;  // LDS row padding in elements (16 bytes)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
     static __device__ __forceinline__ float up(elem e) { return e; }
+    static __device__ __forceinline__ frag ones() { return 1.0f; }   // operand fragment of ones (column sums on the matrix cores)
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float gelu(float x) { return gelu_erf(x); }
     static __device__ __forceinline__ float gelu_grad(float x) { return gelu_erf_grad(x); }
@@ -105,6 +106,12 @@ struct PBF16 {
     static constexpr int PADE = 8;  // 16 bytes
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
     static __device__ __forceinline__ float up(elem e) { return bf2f(e); }
+    static __device__ __forceinline__ frag ones() {
+        s16x8 r;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r[i] = (short)0x3F80;   // bf16 1.0
+        return r;
+    }
     static __device__ __forceinline__ float exp(float x) { return __expf(x); }   // v_exp_f32; probabilities are rounded to bf16 anyway
     static __device__ __forceinline__ float gelu(float x) { return gelu_fast(x); }
     static __device__ __forceinline__ float gelu_grad(float x) { return gelu_fast_grad(x); }
