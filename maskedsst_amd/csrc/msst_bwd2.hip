@@ -19,6 +19,29 @@
 #include "msst_dev.h"
 #include "msst_kernels.h"
 
+#ifndef MSST_B2_PERM
+#define MSST_B2_PERM 0   // measured: 12 % fewer bank-conflict cycles, 4 % slower
+#endif
+#if MSST_B2_PERM
+#define B2_LDKS ld_ks_perm
+#define B2_LDKC ld_kc_perm
+#else
+#define B2_LDKS ld_ks
+#define B2_LDKC ld_kc
+#endif
+
+#ifndef MSST_B2_PRIO
+#define MSST_B2_PRIO 1   // s_setprio level of the MFMA-dense phases (A, C, D); the row-local VALU phases run at 0: -3 %
+#endif
+#if MSST_B2_PRIO
+#define B2_PRIO(n) __builtin_amdgcn_s_setprio((n) ? MSST_B2_PRIO : 0)
+#else
+#define B2_PRIO(n) do { } while (0)
+#endif
+#ifndef MSST_B2_PRIOB
+#define MSST_B2_PRIOB 0   // also raise the priority for the O / dO / dP MFMA bursts of phase B
+#endif
+
 namespace msst {
 
 namespace {
@@ -164,6 +187,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         STAMP(1);
         lds_barrier();
         STAMP(2);
+        B2_PRIO(1);
         // ---------------- phase A: q, k, v^T (wave <-> 16 head channels) ----------------
         {
             f32x4 cq[4], ck[4], cv[4];
@@ -195,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         STAMP(3);
         lds_barrier();
         STAMP(4);
+        B2_PRIO(0);
         // ---------------- phase B: wave <-> 16 query rows ----------------
         f32x4 pr[4];          // raw probabilities (C layout [key][query])
         frag pb[2];           // dropped probabilities, packed as the B operand of key chunk m (permuted key order)
@@ -278,6 +303,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         for (int t = 0; t < 4; ++t) fv[1][t] = P::ld_kc_perm(&sm.vt[t * 16][32], LDH);
         MSST_SCHED_FENCE();
         STAMP(5);
+        if (MSST_B2_PRIOB) B2_PRIO(1);
         frag dob[2];   // dO^T of this wave's queries, packed as the B operand of channel chunk m (permuted order)
         {
             // o = P v  (C[i = d][j = query]) and dO = Wout_h^T da (C[i = d][j = query])
@@ -329,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dp[t] = P::mma(fz[s][t], dob[s], dp[t]);
                 });
+            if (MSST_B2_PRIOB) B2_PRIO(0);
             if (a.drop.thr) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dp[t] = drop4_bits(a.drop, keep1 >> (4 * t), dp[t]);
@@ -350,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         STAMP(7);
         lds_barrier();
         STAMP(8);
+        B2_PRIO(1);
         // ---------------- phase C: contractions over all 64 queries / keys ----------------
         // C1: dWout_h and dv (reads xd = da, o, p, dO); dv -> vt (dead since phase B)
         {
@@ -363,14 +391,14 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             swpipe<8, 2>(
                 [&](int s) {
                     const int ks = s >> 2, j = s & 3;
-                    if (j == 0) fo[ks] = P::ld_ks(&sm.o[ks * 32][wave * 16], LDH);
-                    if (j == 2) fp[ks] = P::ld_ks(&sm.p[ks * 32][wave * 16], LDH);
+                    if (j == 0) fo[ks] = P::B2_LDKS(&sm.o[ks * 32][wave * 16], LDH);
+                    if (j == 2) fp[ks] = P::B2_LDKS(&sm.p[ks * 32][wave * 16], LDH);
                     if (j < 2) {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) fz[s % 3][i] = P::ld_ks(&sm.xd[ks * 32][(3 * j + i) * 16], LDX);
+                        for (int i = 0; i < 3; ++i) fz[s % 3][i] = P::B2_LDKS(&sm.xd[ks * 32][(3 * j + i) * 16], LDX);
                     } else {
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) fz[s % 3][i] = P::ld_ks(&sm.dO[ks * 32][(2 * (j - 2) + i) * 16], LDH);
+                        for (int i = 0; i < 2; ++i) fz[s % 3][i] = P::B2_LDKS(&sm.dO[ks * 32][(2 * (j - 2) + i) * 16], LDH);
                     }
                 },
                 [&](int s) {
@@ -401,12 +429,12 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             swpipe<8, 3>(
                 [&](int s) {
                     const int ks = s >> 2, j = s & 3;
-                    if (j == 0) fs[ks] = P::ld_ks(&sm.ds[ks * 32][wave * 16], LDH);
-                    if (j == 2) fr[ks] = P::ld_kc(&sm.ds[wave * 16][ks * 32], LDH);
+                    if (j == 0) fs[ks] = P::B2_LDKS(&sm.ds[ks * 32][wave * 16], LDH);
+                    if (j == 2) fr[ks] = P::B2_LDKC(&sm.ds[wave * 16][ks * 32], LDH);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
-                        fz[s % 4][i] = j < 2 ? P::ld_ks(&sm.q[ks * 32][(2 * j + i) * 16], LDH)
-                                             : P::ld_ks(&sm.k[ks * 32][(2 * (j - 2) + i) * 16], LDH);
+                        fz[s % 4][i] = j < 2 ? P::B2_LDKS(&sm.q[ks * 32][(2 * j + i) * 16], LDH)
+                                             : P::B2_LDKS(&sm.k[ks * 32][(2 * (j - 2) + i) * 16], LDH);
                 },
                 [&](int s) {
                     const int ks = s >> 2, j = s & 3;
@@ -455,11 +483,11 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
                 [&](int s) {
                     const int ks = s / 6, t = s % 6;
                     if (t == 0) {
-                        fa[ks][0] = P::ld_ks(&sm.o[ks * 32][wave * 16], LDH);
-                        fa[ks][1] = P::ld_ks(&sm.p[ks * 32][wave * 16], LDH);
-                        fa[ks][2] = P::ld_ks(&sm.vt[ks * 32][wave * 16], LDH);
+                        fa[ks][0] = P::B2_LDKS(&sm.o[ks * 32][wave * 16], LDH);
+                        fa[ks][1] = P::B2_LDKS(&sm.p[ks * 32][wave * 16], LDH);
+                        fa[ks][2] = P::B2_LDKS(&sm.vt[ks * 32][wave * 16], LDH);
                     }
-                    fx[s % 4] = P::ld_ks(&sm.xd[ks * 32][t * 16], LDX);
+                    fx[s % 4] = P::B2_LDKS(&sm.xd[ks * 32][t * 16], LDX);
                 },
                 [&](int s) {
                     const int ks = s / 6, t = s % 6;
@@ -505,6 +533,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
 #pragma unroll
             for (int t = 0; t < 6; ++t) P::st_nat(&sm.xd[wave * 16][t * 16], LDX, dx[t]);
         }
+        B2_PRIO(0);
         __builtin_amdgcn_wave_barrier();
         {
             const int t3 = launder(tid);
