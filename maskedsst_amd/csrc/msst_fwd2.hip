@@ -36,6 +36,9 @@
 #ifndef MSST_F2_RING
 #define MSST_F2_RING 4
 #endif
+#ifndef MSST_F2_PRIO
+#define MSST_F2_PRIO 0
+#endif
 
 namespace msst {
 
@@ -157,15 +160,22 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
     }
 
     constexpr int NR = MSST_F2_RING;
-    static_assert(NR == 4, "the out-projection / next-tile hand-over below assumes a ring of four pairs");   // pairs in flight: a pair is requested NR * 8 MFMAs of this wave before its use
+    static_assert(NR == 4 || 18 % NR == 0, "the out-projection / next-tile hand-over below assumes a ring of four pairs");   // pairs in flight: a pair is requested NR * 8 MFMAs of this wave before its use
     frag ring[NR][2];
+    // pair to request into slot pi % NR once pair pi is consumed: NR ahead in the 18-pair stream of a tile, wrapping to the
+    // next tile's first pairs (pair p always lives in slot p % NR: automatic when NR divides 18, hand-placed for NR = 4)
+    auto next_pair = [](int pi) { return 18 % NR == 0 ? (pi + NR) % 18 : (pi + NR < 18 ? pi + NR : pi % NR); };
 #pragma unroll
     for (int pi = 0; pi < NR; ++pi) load_pair(pi, ring[pi], wqkv, wout, H, h, voff);
 
 #ifdef MSST_STAMPS
-    const bool stamp_on = (a.dbg & 8) && blockIdx.x == 100 && tid == MSST_F2_STAMP_TID;
+    const bool stamp_wg = (a.dbg & 8) && blockIdx.x == 100 && tid == MSST_F2_STAMP_TID;
 #endif
+    if (MSST_F2_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every age arbitration otherwise
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+#ifdef MSST_STAMPS
+        const bool stamp_on = stamp_wg && tile == blockIdx.x + 8 * (int)gridDim.x;   // a mid-walk tile
+#endif
         STAMP(0);
         int t1 = threadIdx.x;
         asm volatile("" : "+v"(t1));
@@ -196,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             }
         }
         lds_barrier();
+        if (MSST_F2_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         // ================= head h, all in this wave's registers =================
         // Weight fragments arrive through a ring of six fragment pairs (see load_pair): the pair consumed now was
         // requested six pairs = 48 MFMAs of this wave ago.
@@ -224,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(pi + NR < 18 ? pi + NR : pi % NR, ring[pi % NR], wqkv, wout, H, h, voff);   // >= 18: the next tile's pair pi % NR
+                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, h, voff);   // past pair 17: the next tile's first pairs
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(pi + NR < 18 ? pi + NR : pi % NR, ring[pi % NR], wqkv, wout, H, h, voff);   // >= 18: the next tile's pair pi % NR
+                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, h, voff);   // past pair 17: the next tile's first pairs
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     vA[2 * mm][0] = pack2(cl[0], cl[1]);     vA[2 * mm][1] = pack2(cl[2], cl[3]);
@@ -255,6 +266,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             }
         }
         STAMP(9);
+        if (MSST_F2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         // ================= attention of head h for the four query tiles; O rows go to the shared bf16 tile =================
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

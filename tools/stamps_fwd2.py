@@ -16,9 +16,11 @@ for _ in range(2):
     acts, _ = eng.blocks_fwd(x0, save=True)
 torch.cuda.synchronize()
 s = buf.cpu().numpy()
-names = ["tile start", "LN1 done", "barrier", "q m=0 start", "q m=1", "k m=0", "k m=1", "v mm=0", "v mm=1", "phase A done",
-         "attention done", "out-proj done", "barrier (w<4)", "barrier", "LN2 phase", "barrier", "MLP done", "final barrier"]
+names = ["tile start", "-", "-", "q m=0 start", "q m=1", "k m=0", "k m=1", "v mm=0", "v mm=1", "phase A done",
+         "attention + O stores", "x requests + barrier (O complete)", "out-proj + exchange store", "barrier", "epilogue + LN2 (1 barrier inside)",
+         "barrier", "MLP (1 barrier inside)", "end"]
 prev = s[0]
 for i, n in enumerate(names):
+    if n == '-': continue
     print(f"{n:18s} +{s[i]-prev:7d}  (t={s[i]-s[0]})")
     prev = s[i]
