@@ -348,6 +348,13 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) xv[i] = reinterpret_cast<const f32x4*>(xn_row)[i];
         }
+        // all 24 out-projection weight fragments of this wave's (feature half, K half) are requested before the barrier:
+        // the wait for the slowest head hides their L2 round trip (q / k / v registers are free)
+        frag fw[8][3];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * mh + i) * 16, (8 * kh + s8) * 32);
         lds_barrier();   // O complete
         STAMP(11);
         // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------
@@ -357,20 +364,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) acc[jj][i] = zero4();
         {
-            frag fo[3][2], fw[3][3];   // O row fragments / Wout fragments of a k-step, requested two k-steps ahead
-            swpipe<8, 2>(
+            frag fo[4][2];   // O row fragments of a k-step, requested three k-steps ahead
+            swpipe<8, 3>(
                 [&](int s8) {
                     const int k0 = (8 * kh + s8) * 32;
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) fw[s8 % 3][i] = P::ld_w(wout, inner, (3 * mh + i) * 16, k0);
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) fo[s8 % 3][jj] = P::ld_kc(&sm.ob[(2 * rh + jj) * 16][k0], LDO);
+                    for (int jj = 0; jj < 2; ++jj) fo[s8 % 4][jj] = P::ld_kc(&sm.ob[(2 * rh + jj) * 16][k0], LDO);
                 },
                 [&](int s8) {
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[jj][i] = P::mma(fw[s8 % 3][i], fo[s8 % 3][jj], acc[jj][i]);
+                        for (int i = 0; i < 3; ++i) acc[jj][i] = P::mma(fw[s8][i], fo[s8 % 4][jj], acc[jj][i]);
                 });
         }
         // the other K half of the row tile this wave gives away goes to its owner (wave ^ 4), lane-linear
@@ -434,13 +439,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
         {
             f32x4 hh[2];
             hh[0] = zero4(); hh[1] = zero4();
+            frag xb[3], w1f[2][3];   // all nine operand fragments requested before the first MFMA
 #pragma unroll
             for (int ks = 0; ks < 3; ++ks) {
-                const frag xb = P::ld_kc(&sm.xn[tt * 16][ks * 32], LDX);
+                xb[ks] = P::ld_kc(&sm.xn[tt * 16][ks * 32], LDX);
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
-                    hh[jn] = P::mma(*reinterpret_cast<const frag*>(wmlp + ((2 * half + jn) * 3 + ks) * 1024 + l3 * 16), xb, hh[jn]);
+                for (int jn = 0; jn < 2; ++jn) w1f[jn][ks] = *reinterpret_cast<const frag*>(wmlp + ((2 * half + jn) * 3 + ks) * 1024 + l3 * 16);
             }
+            MSST_SCHED_FENCE();
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) hh[jn] = P::mma(w1f[jn][ks], xb[ks], hh[jn]);
 #pragma unroll
             for (int jn = 0; jn < 2; ++jn) {
                 const int n0 = (2 * half + jn) * 16 + 4 * g3;
@@ -455,13 +465,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             f32x4 yy[3];
 #pragma unroll
             for (int jm = 0; jm < 3; ++jm) yy[jm] = zero4();
+            frag hbf[2], w2f[3][2];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const frag hbf = P::ld_kc(&sm.hb[tt * 16][ks * 32], LDH);
+                hbf[ks] = P::ld_kc(&sm.hb[tt * 16][ks * 32], LDH);
 #pragma unroll
-                for (int jm = 0; jm < 3; ++jm)
-                    yy[jm] = P::mma(*reinterpret_cast<const frag*>(wmlp + (12 + (3 * half + jm) * 2 + ks) * 1024 + l3 * 16), hbf, yy[jm]);
+                for (int jm = 0; jm < 3; ++jm) w2f[jm][ks] = *reinterpret_cast<const frag*>(wmlp + (12 + (3 * half + jm) * 2 + ks) * 1024 + l3 * 16);
             }
+            MSST_SCHED_FENCE();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int jm = 0; jm < 3; ++jm) yy[jm] = P::mma(w2f[jm][ks], hbf[ks], yy[jm]);
             if (tok >= 0) {
 #pragma unroll
                 for (int jm = 0; jm < 3; ++jm) {
