@@ -126,8 +126,8 @@ typedef struct MsstBlockGrads {
  * -> attention half, one workgroup per (tile chunk, head), weight grads in registers -> LN1
  * backward + residual; partial-gradient slabs are reduced in a fixed order (deterministic).
  * Workspace (caller-owned, device): dx1 [tokens][96] f32; dxn_part heads*tokens*96 elems
- * (f32 or bf16 by prec); slab grid_rows*(MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB
- * floats. */
+ * (f32 or bf16 by prec); slab grid_rows*(2*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB
+ * floats (the bf16 MLP half runs up to 2*grid_rows workgroups, one slab each). */
 int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/, const float* x,
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
                    int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,

@@ -247,9 +247,12 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     const BlockWeights bw = to_bw(w);
     const Drop drop = make_drop(dropout_p, seed, layer);
     const int ntiles_rows = (int)((ntok + 63) / 64);
-    const int grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;
+    const int grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;   // LN1 backward: HBM bound at one workgroup per CU
+    // the bf16 MLP backward is latency bound and fits two workgroups per CU: twice the persistent grid (and slabs)
+    const int gmlp2 = (prec == MSST_PREC_BF16 && PBF16::WAVES_BWD_MLP == 2) ? 2 * grid_rows : grid_rows;
+    const int grid_mlp = gmlp2 < ntiles_rows ? gmlp2 : ntiles_rows;
     float* slab_mlp = slab;
-    float* slab_attn = slab_mlp + (long)grid * MSST_MLP_SLAB_N;
+    float* slab_attn = slab_mlp + (long)grid_mlp * MSST_MLP_SLAB_N;
     AttnBwdArgs aa;
     aa.tm = make_tilemap(mode, B, S, N);
     aa.ntiles = ntiles_of(aa.tm);
@@ -259,7 +262,7 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     {
         MlpBwdArgs a;
         a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok; a.drop = drop;
-        int rc = launch_block_bwd_mlp(a, grid, prec, st);
+        int rc = launch_block_bwd_mlp(a, grid_mlp, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
     }
     // 2. attention half, per (chunk, head)
@@ -283,12 +286,12 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     {
         RSegBuilder rb;
         const long ms = MSST_MLP_SLAB_N;
-        bool ok = rb.add(slab_mlp, ms, grid, g->w1, 6144);
-        ok = ok && rb.add(slab_mlp + 6144, ms, grid, g->w2, 6144);
-        ok = ok && rb.add(slab_mlp + 12288, ms, grid, g->b1, 64);
-        ok = ok && rb.add(slab_mlp + 12288 + 64, ms, grid, g->b2, 96);
-        ok = ok && rb.add(slab_mlp + 12288 + 160, ms, grid, g->ln2_g, 96);
-        ok = ok && rb.add(slab_mlp + 12288 + 256, ms, grid, g->ln2_b, 96);
+        bool ok = rb.add(slab_mlp, ms, grid_mlp, g->w1, 6144);
+        ok = ok && rb.add(slab_mlp + 6144, ms, grid_mlp, g->w2, 6144);
+        ok = ok && rb.add(slab_mlp + 12288, ms, grid_mlp, g->b1, 64);
+        ok = ok && rb.add(slab_mlp + 12288 + 64, ms, grid_mlp, g->b2, 96);
+        ok = ok && rb.add(slab_mlp + 12288 + 160, ms, grid_mlp, g->ln2_g, 96);
+        ok = ok && rb.add(slab_mlp + 12288 + 256, ms, grid_mlp, g->ln2_b, 96);
         ok = ok && rb.add(slab_ln1, 288, grid, g->ln1_g, 96);
         ok = ok && rb.add(slab_ln1 + 96, 288, grid, g->ln1_b, 96);
         ok = ok && rb.add(slab_ln1 + 192, 288, grid, g->bo, 96);

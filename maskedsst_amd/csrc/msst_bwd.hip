@@ -144,7 +144,7 @@ struct MlpBwdSmem {
 };
 
 template <class P>
-__global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     typedef typename P::elem elem;
     typedef typename P::frag frag;
     typedef MlpBwdSmem<P> SM;
@@ -174,11 +174,14 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     // bf16: the three weight matrices (36 fragment-packed KB) stay in LDS for the life of the workgroup and the
     // next tile's rows are requested one tile ahead (this kernel runs 1 wave/SIMD: registers are plentiful)
     constexpr bool BF = sizeof(elem) == 2;
+    constexpr bool TWO = BF && P::WAVES_BWD_MLP == 2;   // two workgroups per CU: w1T from L2 (LDS 71 KB), rows not prefetched
+    constexpr bool PREF = BF && !TWO;
+    constexpr int NST = TWO ? 6 : 9;
     char* wl = smem_raw + sizeof(SM) + 256 * sizeof(float);   // [w1 12 | w2T 12 | w1T 12] fragments of 1 KB
     if constexpr (BF) {
 #pragma unroll
-        for (int i9 = 0; i9 < 9; ++i9) {
-            const int f = wave * 9 + i9;
+        for (int i9 = 0; i9 < NST; ++i9) {
+            const int f = wave * NST + i9;
             const char* src = f < 12 ? reinterpret_cast<const char*>(w1) + f * 1024
                             : f < 24 ? reinterpret_cast<const char*>(w2T) + (f - 12) * 1024
                                      : reinterpret_cast<const char*>(w1T) + (f - 24) * 1024;
@@ -188,6 +191,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     }
     __syncthreads();
     auto wfrag = [&](int which, const elem* wg, int K, int row0, int k0) -> frag {
+        if (TWO && which == 2) return P::ld_w(wg, K, row0, k0);
         if constexpr (BF) {
             const int f = which * 12 + (row0 >> 4) * (K >> 5) + (k0 >> 5);
             return *reinterpret_cast<const frag*>(wl + f * 1024 + l * 16);
@@ -198,7 +202,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
 
     const int ntiles = (a.ntok + 63) / 64;
     f32x4 xpre[6], dpre[6];
-    if constexpr (BF) {
+    if constexpr (PREF) {
         const long tok0 = (long)blockIdx.x * 64 + wave * 16 + c;
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void block_bwd_mlp_kernel(MlpBwdArgs a) {
         for (int mt = 0; mt < 6; ++mt) {
             const int m0 = mt * 16 + 4 * g;
             f32x4 xr = zero4(), dr = zero4();
-            if constexpr (BF) {
+            if constexpr (PREF) {
                 xr = xpre[mt]; dr = dpre[mt];
                 const long tokn = tok + (long)gridDim.x * 64;   // same rows of this workgroup's next tile
                 const bool vn = tile + (int)gridDim.x < ntiles && tokn < a.ntok;
@@ -1335,7 +1339,7 @@ int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st
         ProfScope ps(K_BWD_MLP, st);
         hipLaunchKernelGGL(block_bwd_mlp_kernel<PF32>, dim3(grid), dim3(256), smem, st, a);
     } else {
-        const size_t smem = sizeof(MlpBwdSmem<PBF16>) + 256 * sizeof(float) + 36 * 1024;
+        const size_t smem = sizeof(MlpBwdSmem<PBF16>) + 256 * sizeof(float) + (PBF16::WAVES_BWD_MLP == 2 ? 24 : 36) * 1024;
         int rc = set_smem(&block_bwd_mlp_kernel<PBF16>, smem, d1);
         if (rc) return rc;
         ProfScope ps(K_BWD_MLP, st);

@@ -53,6 +53,7 @@ struct PF32 {
     static constexpr int UNROLL = 2;          // k-loop unroll (24 / 16 steps per GEMM)
     static constexpr int WAVES_PER_SIMD = 1;  // launch-bounds occupancy target (LDS allows 1 WG/CU)
     static constexpr int WAVES_BWD_ATTN = 1;
+    static constexpr int WAVES_BWD_MLP = 1;
     static constexpr int PADE = 4;  // LDS row padding in elements (16 bytes)
     static __device__ __forceinline__ elem cvt(float f) { return f; }
     static __device__ __forceinline__ float up(elem e) { return e; }
@@ -103,6 +104,10 @@ struct PBF16 {
     static constexpr int UNROLL = MSST_BF_UNROLL;   // k-loops have 2-3 steps; full unrolling only inflates registers
     static constexpr int WAVES_PER_SIMD = 2;
     static constexpr int WAVES_BWD_ATTN = 2;  // 2 workgroups per CU (LDS 76 KB each)
+#ifndef MSST_MLP2
+#define MSST_MLP2 1
+#endif
+    static constexpr int WAVES_BWD_MLP = MSST_MLP2 ? 2 : 1;   // MSST_MLP2: two workgroups per CU (w1T fragments from L2, no row prefetch)
     static constexpr int PADE = 8;  // 16 bytes
     static __device__ __forceinline__ elem cvt(float f) { return f2bf(f); }
     static __device__ __forceinline__ float up(elem e) { return bf2f(e); }

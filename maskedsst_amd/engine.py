@@ -241,7 +241,8 @@ class Engine:
         esz = 4 if self.prec == PREC_F32 else 2
         dx1 = torch.empty(ntok * 96, dtype=torch.float32, device=dev)
         part = torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev)
-        nslab = self.grid_rows * (MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
+        # the bf16 MLP backward runs two workgroups per CU: up to 2 * grid_rows MLP slabs (msst_block_bwd lays the parts out)
+        nslab = self.grid_rows * (2 * MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
         slab = torch.empty(nslab, dtype=torch.float32, device=dev)
         layers = self._layers()
         g = dy
