@@ -98,6 +98,7 @@ static Drop make_drop(float p, uint32_t seed, int layer) {
     d.seed = seed; d.layer = layer;
     if (p > 0.f) {
         d.thr = (unsigned)(p * 65536.0f + 0.5f);
+        if (d.thr > 65535u) d.thr = 65535u;   // the kernels test whole words against thr << 16 (p >= 1 is degenerate anyway)
         d.scale = 1.0f / (1.0f - (float)d.thr / 65536.0f);   // exact inverse of the realised keep probability
     } else {
         d.thr = 0; d.scale = 1.0f;

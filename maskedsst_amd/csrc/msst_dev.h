@@ -325,14 +325,29 @@ __device__ __forceinline__ void drop_bits(const Drop& d, int site, unsigned grou
     b = x * 0xC2B2AE35U; b ^= b >> 16;
 }
 // site: 1 = attention probabilities, 2 = to_out, 3 = MLP hidden, 4 = MLP out
+// The field tests are written on the full word: hi field >= thr <=> word >= thr << 16, lo field >= thr <=> word << 16 >= thr << 16
+// (same decisions, no field extraction: one shift for the two lo fields instead of two ands and two shifts).
 __device__ __forceinline__ f32x4 drop4(const Drop& d, int site, unsigned group, f32x4 v) {
     unsigned a, b;
     drop_bits(d, site, group, a, b);
+    const unsigned t16 = d.thr << 16;
     f32x4 r;
-    r[0] = (a & 0xffffU) >= d.thr ? v[0] * d.scale : 0.f;
-    r[1] = (a >> 16) >= d.thr ? v[1] * d.scale : 0.f;
-    r[2] = (b & 0xffffU) >= d.thr ? v[2] * d.scale : 0.f;
-    r[3] = (b >> 16) >= d.thr ? v[3] * d.scale : 0.f;
+    r[0] = (a << 16) >= t16 ? v[0] * d.scale : 0.f;
+    r[1] = a >= t16 ? v[1] * d.scale : 0.f;
+    r[2] = (b << 16) >= t16 ? v[2] * d.scale : 0.f;
+    r[3] = b >= t16 ? v[3] * d.scale : 0.f;
+    return r;
+}
+// same masks, kept values NOT scaled (the caller folded 1 / (1 - p) into a factor it applies anyway)
+__device__ __forceinline__ f32x4 drop4_noscale(const Drop& d, int site, unsigned group, f32x4 v) {
+    unsigned a, b;
+    drop_bits(d, site, group, a, b);
+    const unsigned t16 = d.thr << 16;
+    f32x4 r;
+    r[0] = (a << 16) >= t16 ? v[0] : 0.f;
+    r[1] = a >= t16 ? v[1] : 0.f;
+    r[2] = (b << 16) >= t16 ? v[2] : 0.f;
+    r[3] = b >= t16 ? v[3] : 0.f;
     return r;
 }
 // same, also returning the four keep decisions as bits 0..3 (the attention backward reuses them for dP)

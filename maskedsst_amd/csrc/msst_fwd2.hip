@@ -305,12 +305,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
             sum = colgroup_sum(sum);
-            const float inv = 1.f / sum;
+            const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 s[t] = s[t] * inv;
                 if (a.drop.thr)
-                    s[t] = drop4(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
+                    s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
             }
             const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
             f32x4 o[4];
