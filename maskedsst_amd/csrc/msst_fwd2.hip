@@ -39,6 +39,9 @@
 #ifndef MSST_F2_PRIO
 #define MSST_F2_PRIO 0
 #endif
+#ifndef MSST_F2_SKIP
+#define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
+#endif
 
 namespace msst {
 
@@ -151,6 +154,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
     int qlo[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) qlo[j] = ((j * 16 + c) / L) * L;
+    // short sequences (spectral blocks): query tile j only meets the key tiles that overlap the sequences of its 16 rows --
+    // bit t of need[j]; every other 16 x 16 score tile is masked anyway and is skipped (MFMAs, exps, dropout hashes)
+    unsigned need[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int s_lo = (16 * j) / L, s_hi = min((16 * j + 15) / L, tm.TS - 1);
+        const int k_lo = s_lo * L, k_hi = (s_hi + 1) * L - 1;   // s_lo >= TS (all-padding query tile): empty range
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m |= (unsigned)(s_lo <= s_hi && 16 * t <= k_hi && 16 * t + 15 >= k_lo) << t;
+        need[j] = MSST_F2_SKIP ? m : 0xfu;
+    }
 
     f32x4 xv[3];   // this thread's 12 row values of the tile to process (prefetched one tile ahead)
     {
@@ -271,53 +286,91 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             f32x4 s[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s[t] = P::mma(kA[t][0], qB[j][0], zero4());   // C[i = key][j = query]
-                s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
-            }
-            // softmax over the keys of the query's own sequence.  exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e:
-            // one FMA + one v_exp per element; with 64-token sequences (spatial blocks) nothing is masked
+            f32x4 o[4];
             const float cs = a.scale * 1.44269504088896340736f;
-            float mx = -INFINITY;
             if (L == 64) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s[t] = P::mma(kA[t][0], qB[j][0], zero4());   // C[i = key][j = query]
+                    s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
+                }
+                // softmax over the 64 keys.  exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e: one FMA + one v_exp
+                // per element, nothing to mask
+                float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-            } else {
-                const int lo = qlo[j], hi = lo + L;
+                mx = colgroup_max(mx);
+                const float mc = mx * cs;
+                float sum = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = t * 16 + 4 * g + r;
-                        const float v = (key >= lo && key < hi) ? s[t][r] : -INFINITY;
-                        s[t][r] = v;
-                        mx = fmaxf(mx, v);
+                    for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
+                sum = colgroup_sum(sum);
+                const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s[t] = s[t] * inv;
+                    if (a.drop.thr)
+                        s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
+                }
+                const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
+#pragma unroll
+                for (int dd = 0; dd < 4; ++dd) {
+                    o[dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
+                    o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+                }
+            } else {
+                // several short sequences per tile: keys outside the query's own sequence are masked; key tiles that no row of
+                // this query tile can see are skipped altogether
+                const unsigned nm = need[j];
+                const int lo = qlo[j], hi = lo + L;
+                float mx = -INFINITY;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if ((nm >> t) & 1u) {
+                        s[t] = P::mma(kA[t][0], qB[j][0], zero4());
+                        s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = t * 16 + 4 * g + r;
+                            const float v = (key >= lo && key < hi) ? s[t][r] : -INFINITY;
+                            s[t][r] = v;
+                            mx = fmaxf(mx, v);
+                        }
                     }
-            }
-            mx = colgroup_max(mx);
-            const float mc = mx * cs;
-            float sum = 0.f;
+                }
+                mx = colgroup_max(mx);
+                const float mc = mx * cs;
+                float sum = 0.f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if ((nm >> t) & 1u) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
-            sum = colgroup_sum(sum);
-            const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
+                        for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
+                    } else {
+                        s[t] = zero4();
+                    }
+                }
+                sum = colgroup_sum(sum);
+                const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s[t] = s[t] * inv;
-                if (a.drop.thr)
-                    s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
-            }
-            const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
-            f32x4 o[4];
+                for (int t = 0; t < 4; ++t) {
+                    if ((nm >> t) & 1u) {
+                        s[t] = s[t] * inv;
+                        if (a.drop.thr)
+                            s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
+                    }
+                }
+                const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
 #pragma unroll
-            for (int dd = 0; dd < 4; ++dd) {
-                o[dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
-                o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+                for (int dd = 0; dd < 4; ++dd) {
+                    o[dd] = zero4();
+                    if (nm & 3u) o[dd] = P::mma(vA[dd][0], p0, o[dd]);
+                    if (nm & 12u) o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+                }
             }
             // pack2(o[2u], o[2u + 1]) holds, in lane (c, g), the natural channels 32 u + 8 g .. + 7 of query row 16 j + c:
             // one 16-byte store per half
