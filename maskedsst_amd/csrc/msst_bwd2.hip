@@ -93,17 +93,20 @@ __device__ __forceinline__ void ln_pack(const f32x4 (&xv)[6], const float* lnp, 
 }
 
 // da rows: dropout site 2 backward (same element groups as the forward) and bf16 packing
+template <bool DROP>
 __device__ __forceinline__ void da_pack(const f32x4 (&dav)[6], const Drop& drop, long tok, int lpart, s16x4 (&out)[6]) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         f32x4 t4 = tok >= 0 ? dav[i] : zero4();
-        if (drop.thr && tok >= 0) t4 = drop4(drop, 2, (unsigned)(tok * 24 + lpart * 6 + i), t4);
+        if (DROP && tok >= 0) t4 = drop4(drop, 2, (unsigned)(tok * 24 + lpart * 6 + i), t4);
         out[i] = f2bf4(t4);
     }
 }
 
 }  // namespace
 
+// DROP: dropout compiled in / out (uniform run-time tests would split the instruction stream into basic blocks)
+template <bool DROP>
 __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs a) {
     typedef Bwd2Smem SM;
     constexpr int LDX = SM::LDX, LDH = SM::LDH;
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             for (int i = 0; i < 6; ++i) xv[i] = zero4();
         }
         ln_pack(xv, lnp, tid & 3, xnk);
-        da_pack(dav, a.drop, tok0, tid & 3, dak);
+        da_pack<DROP>(dav, a.drop, tok0, tid & 3, dak);
     }
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             for (int t = 0; t < 4; ++t) {
                 pr[t] = pr[t] * inv;
                 f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
-                if (a.drop.thr) {
+                if (DROP) {
                     unsigned kb;
                     pd = drop4_keep(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c) * 16 + t * 4 + g), pd, kb);
                     keep1 |= kb << (4 * t);   // the 16 keep decisions of this lane, reused for dP below
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
                     for (int t = 0; t < 4; ++t) dp[t] = P::mma(fz[s][t], dob[s], dp[t]);
                 });
             if (MSST_B2_PRIOB) B2_PRIO(0);
-            if (a.drop.thr) {
+            if (DROP) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) dp[t] = drop4_bits(a.drop, keep1 >> (4 * t), dp[t]);
             }
@@ -555,7 +558,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             for (int i = 0; i < 6; ++i) xv[i] = zero4();
         }
         ln_pack(xv, lnp, launder(tid) & 3, xnk);
-        da_pack(dav, a.drop, tok_of(tile + gridDim.x), launder(tid) & 3, dak);
+        da_pack<DROP>(dav, a.drop, tok_of(tile + gridDim.x), launder(tid) & 3, dak);
         STAMP(16);
         // no block barrier here: the next tile's first stores only touch this wave's own xd rows, and q / k / vt
         // are not written before the barrier that follows them
@@ -580,13 +583,17 @@ int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st)
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     const size_t smem = sizeof(Bwd2Smem) + 192 * sizeof(float);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_attn_bf16_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_attn_bf16_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_attn_bf16_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    hipLaunchKernelGGL(block_bwd_attn_bf16_kernel, dim3(nchunk, a.H), dim3(256), smem, st, a);
+    if (a.drop.thr) hipLaunchKernelGGL(block_bwd_attn_bf16_kernel<true>, dim3(nchunk, a.H), dim3(256), smem, st, a);
+    else hipLaunchKernelGGL(block_bwd_attn_bf16_kernel<false>, dim3(nchunk, a.H), dim3(256), smem, st, a);
     return (int)hipGetLastError();
 }
 

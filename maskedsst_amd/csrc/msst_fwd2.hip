@@ -106,6 +106,9 @@ __device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wq
 
 }  // namespace
 
+// DROP: dropout compiled in / out (a uniform run-time test at every site splits the instruction stream into basic blocks the
+// scheduler cannot interleave across)
+template <bool DROP>
 __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
     typedef Fwd2Smem SM;
     constexpr int LDX = SM::LDX, LDH = SM::LDH, LDO = SM::LDO;
@@ -309,11 +312,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
                 sum = colgroup_sum(sum);
-                const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
+                const float inv = (DROP ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     s[t] = s[t] * inv;
-                    if (a.drop.thr)
+                    if (DROP)
                         s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
                 }
                 const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
@@ -355,12 +358,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                     }
                 }
                 sum = colgroup_sum(sum);
-                const float inv = (a.drop.thr ? a.drop.scale : 1.f) / sum;
+                const float inv = (DROP ? a.drop.scale : 1.f) / sum;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if ((nm >> t) & 1u) {
                         s[t] = s[t] * inv;
-                        if (a.drop.thr)
+                        if (DROP)
                             s[t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + j * 16 + c) * 16 + t * 4 + g), s[t]);
                     }
                 }
@@ -455,7 +458,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 f32x4 o4 = (kh == 0 ? acc[0][i] : acc[1][i]) + sm.xch[wave][i][l3];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o4[r] += lnp[192 + m0 + r];
-                if (a.drop.thr && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                if (DROP && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                 o4 = o4 + xr[i];
                 x1r[i] = o4;
                 s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 const int n0 = (2 * half + jn) * 16 + 4 * g3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hh[jn][r] = gelu_fast(hh[jn][r] + lnp[576 + n0 + r]);
-                if (a.drop.thr && tok >= 0) hh[jn] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jn]);
+                if (DROP && tok >= 0) hh[jn] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jn]);
                 P::st_nat(&sm.hb[tt * 16][(2 * half + jn) * 16], LDH, hh[jn]);
             }
         }
@@ -537,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                     f32x4 o4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o4[r] = yy[jm][r] + lnp[480 + m0 + r];
-                    if (a.drop.thr) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                    if (DROP) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                     o4 = o4 + x1r[jm];
                     *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
                 }
@@ -554,13 +557,17 @@ int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st) {
     static bool attr_set = false;
     const size_t smem = sizeof(Fwd2Smem) + 640 * sizeof(float) + 24 * 1024;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_hw_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_hw_kernel<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_hw_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     ProfScope ps(K_BLOCK_FWD, st);
-    hipLaunchKernelGGL(block_fwd_hw_kernel, dim3(grid), dim3(512), smem, st, a);
+    if (a.drop.thr) hipLaunchKernelGGL(block_fwd_hw_kernel<true>, dim3(grid), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL(block_fwd_hw_kernel<false>, dim3(grid), dim3(512), smem, st, a);
     return (int)hipGetLastError();
 }
 
