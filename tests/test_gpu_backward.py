@@ -102,3 +102,37 @@ def test_param_grads_bf16(cfg):
         if not e < 5e-2:
             bad.append((name, e))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
+                         ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_attn_bwd_kernels_agree(cfg, monkeypatch):
+    """The tuned bf16 attention backward (msst_bwd2.hip) against the template kernel it was derived from
+    (msst_bwd.hip, MSST_DBG=16): same bf16 operands, same dropout-free arithmetic up to summation order, so every
+    gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and spectral tiles, 64- and
+    short-sequence masking, padding rows)."""
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+
+    def run():
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone())
+        torch.cuda.synchronize()
+        return dx0.clone(), eng.fp.grad.clone()
+
+    dx_new, g_new = run()
+    monkeypatch.setenv("MSST_DBG", "16")
+    dx_old, g_old = run()
+    monkeypatch.delenv("MSST_DBG")
+    assert rel_l2(dx_new, dx_old) < 5e-3
+    bad = []
+    for name, p in eng.trainable():
+        a, b = eng.fp.view(name, g_new), eng.fp.view(name, g_old)
+        if float(b.abs().max()) == 0.0:
+            continue
+        e = rel_l2(a, b)
+        if not e < 5e-3:
+            bad.append((name, e))
+    assert not bad, bad
