@@ -84,10 +84,13 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
  * sequence grouping of vit_spatial_spectral.py:410-431 (no transposes are materialised).
  * x -> y (y != x); x1 (optional) receives x + attn(LN(x)) for the backward.
  * dropout_p > 0 enables the reference's four dropout sites (:38,40,57,62) with a stateless counter-based
- * mask keyed by (seed, layer, site, element); msst_block_bwd regenerates it from the same three values. */
+ * mask keyed by (seed, layer, site, element); msst_block_bwd regenerates it from the same three values.
+ * xn_out (optional, [tokens][96] bf16): receives LN1(x) exactly as the block used it, so that msst_block_bwd neither
+ * re-reads x nor renormalises it; *xn_written (host, optional) tells whether the selected kernel wrote it (only the
+ * bf16 head-per-wave kernel does) -- pass xn_saved to msst_block_bwd only then. */
 int msst_block_fwd(const MsstBlockWeights* w /*host*/, const float* x, float* y, float* x1, int mode,
                    int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed,
-                   int layer, void* stream);
+                   int layer, void* xn_out, int* xn_written /*host*/, void* stream);
 
 /* a12-a14: gather of masked tokens, BlockwiseToPixels (vit_simmim_original.py:9-40,314-330),
  * target gather from the raw cube (:335) and mean-L1 / K (:338).
@@ -131,7 +134,8 @@ typedef struct MsstBlockGrads {
 int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/, const float* x,
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
                    int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,
-                   float dropout_p, uint32_t seed, int layer, void* stream);
+                   float dropout_p, uint32_t seed, int layer, const void* xn_saved /*optional, see msst_block_fwd*/,
+                   void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.
  * slab: S * nchunk * (N*96 + 96*P + 4*96 + 32) floats + S*N*96 floats (position staging).

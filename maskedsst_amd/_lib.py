@@ -48,13 +48,13 @@ _SIGS = {
     "msst_cls_head_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_int, _P]),
     "msst_cls_head_bwd": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_int, _P]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_float, c_uint32, c_int, _P]),
+                               c_int, c_int, c_float, c_uint32, c_int, _P, POINTER(c_int), _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                               c_int, _P]),
     "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
                               c_int, c_int, _P]),
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
-                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P]),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, c_float,
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),

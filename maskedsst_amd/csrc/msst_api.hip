@@ -185,7 +185,7 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
 
 int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x1, int mode, int B, int S,
                    int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed, int layer,
-                   void* stream) {
+                   void* xn_out, int* xn_written, void* stream) {
     if (!w || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (sequence length > 64)");
     BlockArgs a;
@@ -200,6 +200,8 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.stamps = g_stamps;
     if (!g_stamps) a.dbg &= ~8;
     a.drop = make_drop(dropout_p, seed, layer);
+    a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
+    if (xn_written) *xn_written = a.xn_out ? 1 : 0;
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 
@@ -240,7 +242,7 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
 int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
                    const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                    int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                   uint32_t seed, int layer, void* stream) {
+                   uint32_t seed, int layer, const void* xn_saved, void* stream) {
     if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
     hipStream_t st = (hipStream_t)stream;
@@ -268,7 +270,7 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     }
     // 2. attention half, per (chunk, head)
     {
-        aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
+        aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn; aa.xn = xn_saved;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
         { const char* e = getenv("MSST_DBG"); aa.dbg = e ? atoi(e) : 0; }
         aa.stamps = g_stamps;

@@ -106,7 +106,8 @@ __device__ __forceinline__ void da_pack(const f32x4 (&dav)[6], const Drop& drop,
 }  // namespace
 
 // DROP: dropout compiled in / out (uniform run-time tests would split the instruction stream into basic blocks)
-template <bool DROP>
+// XN: the forward saved LN1(x) as bf16 rows (a.xn): they are loaded straight into the packed registers, x is never read
+template <bool DROP, bool XN>
 __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs a) {
     typedef Bwd2Smem SM;
     constexpr int LDX = SM::LDX, LDH = SM::LDH;
@@ -157,18 +158,35 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         for (int i = 0; i < 6; ++i) dst[i] = src[i];
     };
 
+    auto load_xn = [&](long tok, s16x4 (&dst)[6]) {   // 48 bytes of the thread's bf16 row slice, clamped address
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const elem*>(a.xn) + (tok >= 0 ? tok : 0) * 96 + (launder(tid) & 3) * 24);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const u32x4 v = src[i];
+            dst[2 * i] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 0, 1));
+            dst[2 * i + 1] = __builtin_bit_cast(s16x4, __builtin_shufflevector(v, v, 2, 3));
+        }
+    };
+    auto zero_xn = [&](s16x4 (&dst)[6]) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) dst[i] = s16x4{0, 0, 0, 0};
+    };
     s16x4 xnk[6];   // LN1(x) rows of the tile to process, packed (stored at the top of the tile, again before phase D)
     s16x4 dak[6];   // its da rows, dropped and packed (stored after phase A)
     {
         const long tok0 = tok_of(blockIdx.x);
         f32x4 xv[6], dav[6];
-        load_rows(a.x, tok0, xv);
+        if constexpr (XN) load_xn(tok0, xnk); else load_rows(a.x, tok0, xv);
         load_rows(a.da, tok0, dav);
-        if (tok0 < 0) {
+        if constexpr (XN) {
+            if (tok0 < 0) zero_xn(xnk);
+        } else {
+            if (tok0 < 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) xv[i] = zero4();
+                for (int i = 0; i < 6; ++i) xv[i] = zero4();
+            }
+            ln_pack(xv, lnp, tid & 3, xnk);
         }
-        ln_pack(xv, lnp, tid & 3, xnk);
         da_pack<DROP>(dav, a.drop, tok0, tid & 3, dak);
     }
 
@@ -476,7 +494,8 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         }
         // rows of the NEXT tile of this workgroup: requested now, normalised between the two phase-D GEMMs
         f32x4 xv[6];
-        load_rows(a.x, tok_of(tile + gridDim.x), xv);
+        if constexpr (XN) load_xn(tok_of(tile + gridDim.x), xnk);   // the restore above was the last use of this tile's rows
+        else load_rows(a.x, tok_of(tile + gridDim.x), xv);
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
         {
             // dW{q,k,v}[d][m] += sum_row d{q,k,v}[row][d] xn[row][m]    C[i = d tile wave][j = m tile t]
@@ -553,11 +572,19 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             }
         }
         // LN1 of the next tile's rows (requested before the weight-grad GEMM); padding rows normalise zeros
-        if (tok_of(tile + gridDim.x) < 0) {
+        if constexpr (XN) {
+            // pin the arrival of the saved rows HERE (a counted vmcnt in straight-line code): left to the store at the top of
+            // the next iteration, the wait crosses the loop edge, becomes vmcnt(0) and also waits for the stores above
 #pragma unroll
-            for (int i = 0; i < 6; ++i) xv[i] = zero4();
+            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(xnk[i]));
+            if (tok_of(tile + gridDim.x) < 0) zero_xn(xnk);
+        } else {
+            if (tok_of(tile + gridDim.x) < 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xv[i] = zero4();
+            }
+            ln_pack(xv, lnp, launder(tid) & 3, xnk);
         }
-        ln_pack(xv, lnp, launder(tid) & 3, xnk);
         da_pack<DROP>(dav, a.drop, tok_of(tile + gridDim.x), launder(tid) & 3, dak);
         STAMP(16);
         // no block barrier here: the next tile's first stores only touch this wave's own xd rows, and q / k / vt
@@ -582,18 +609,19 @@ int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st)
     static bool attr_set = false;
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     const size_t smem = sizeof(Bwd2Smem) + 192 * sizeof(float);
+    typedef void (*kern_t)(AttnBwdArgs);
+    const kern_t kerns[4] = {&block_bwd_attn_bf16_kernel<false, false>, &block_bwd_attn_bf16_kernel<true, false>,
+                             &block_bwd_attn_bf16_kernel<false, true>, &block_bwd_attn_bf16_kernel<true, true>};
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_attn_bf16_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_attn_bf16_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
+        for (int i = 0; i < 4; ++i) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    if (a.drop.thr) hipLaunchKernelGGL(block_bwd_attn_bf16_kernel<true>, dim3(nchunk, a.H), dim3(256), smem, st, a);
-    else hipLaunchKernelGGL(block_bwd_attn_bf16_kernel<false>, dim3(nchunk, a.H), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.xn ? 2 : 0)], dim3(nchunk, a.H), dim3(256), smem, st, a);
     return (int)hipGetLastError();
 }
 

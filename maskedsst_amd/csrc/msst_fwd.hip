@@ -788,6 +788,10 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
     return launch_block_fwd_bf16(a, grid, st);
 }
 
+bool block_fwd_writes_xn(const BlockArgs& a, int prec) {
+    return prec == MSST_PREC_BF16 && !(a.dbg & 16) && a.H == 8 && !(a.dbg & 64);   // = the head-per-wave kernel is selected above
+}
+
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {
     if (a.P > 16) return MSST_ERR_UNSUPPORTED;
     dim3 grid((a.K + 63) / 64, a.B);

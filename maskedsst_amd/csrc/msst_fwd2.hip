@@ -203,7 +203,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             float v[12];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
-            if (tm.token_sp(tile, tm.row_sp(lr)) < 0) {   // padding row: the prefetch read a clamped address, normalise zeros
+            const long tok_ln = tm.token_sp(tile, tm.row_sp(lr));
+            if (tok_ln < 0) {   // padding row: the prefetch read a clamped address, normalise zeros
 #pragma unroll
                 for (int i = 0; i < 12; ++i) v[i] = 0.f;
             }
@@ -220,7 +221,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 f32x4 n4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[part * 12 + 4*i+e] + lnp[96 + part * 12 + 4*i+e];
-                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 12 + 4 * i]) = f2bf4(n4);
+                const s16x4 nb = f2bf4(n4);
+                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 12 + 4 * i]) = nb;
+                // the same bf16 rows go to HBM for the attention backward (192 contiguous bytes per row from 8 threads)
+                if (a.xn_out && tok_ln >= 0) *reinterpret_cast<s16x4*>(reinterpret_cast<elem*>(a.xn_out) + tok_ln * 96 + part * 12 + 4 * i) = nb;
             }
         }
         lds_barrier();

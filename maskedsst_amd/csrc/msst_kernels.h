@@ -31,6 +31,7 @@ struct BlockArgs {
     const float* x;   // [tokens][96] block input (residual stream, fp32)
     float* y;         // [tokens][96] block output
     float* x1;        // [tokens][96] mid-block residual (x + attn), saved for the backward; may be null
+    void* xn_out;     // optional [tokens][96] bf16: LN1(x) exactly as the block used it, saved for the attention backward (head-per-wave kernel only)
     TileMap tm;
     int ntiles, max_grid, H;
     float scale;      // dim_head^-0.5
@@ -86,6 +87,7 @@ struct MlpBwdArgs {
 struct AttnBwdArgs {
     BlockWeights w;
     const float* x; const float* da; void* dxn_part; float* slab;
+    const void* xn;   // optional [tokens][96] bf16 LN1(x) saved by the forward: the bf16 kernel then neither re-reads x nor renormalises
     TileMap tm;
     int ntiles, H;
     long ntok;
@@ -172,6 +174,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
                  float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd2.hip (bf16, 8 heads)
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
+bool block_fwd_writes_xn(const BlockArgs& a, int prec);   // does the kernel launch_block_fwd selects honour a.xn_out?
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st);
 
 }  // namespace msst

@@ -180,10 +180,17 @@ class Engine:
         for i, (sname, l) in enumerate(self._layers()):
             y = torch.empty_like(x)
             x1 = torch.empty_like(x) if save else None
+            # bf16: the block also saves LN1(x) as it used it (bf16 rows), if the selected kernel can; the attention backward
+            # then skips its own LN1.  The buffer rides on the x1 tensor object so that every caller keeps its (acts, x1s) pair.
+            xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (save and self.prec != PREC_F32) else None
+            wrote = ctypes.c_int(0)
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
             _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec, self.max_grid, drop[0], drop[1], i, _stream()),
+                                               self.prec, self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
+                                               _stream()),
                        "msst_block_fwd")
+            if x1 is not None:
+                x1._msst_xn = xn if wrote.value else None
             acts.append(y)
             x1s.append(x1)
             x = y
@@ -253,7 +260,7 @@ class Engine:
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec,
-                drop[0], drop[1], i, _stream()), "msst_block_bwd")
+                drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g
