@@ -135,6 +135,8 @@ int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
                    int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,
                    float dropout_p, uint32_t seed, int layer, const void* xn_saved /*optional, see msst_block_fwd*/,
+                   void* dab_ws /*optional workspace [tokens][96] bf16, used together with xn_saved: the MLP half leaves the
+                                  dropped bf16 copy of dx1 there for the attention half*/,
                    void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.

@@ -242,7 +242,7 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
 int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
                    const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                    int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                   uint32_t seed, int layer, const void* xn_saved, void* stream) {
+                   uint32_t seed, int layer, const void* xn_saved, void* dab_ws, void* stream) {
     if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
     hipStream_t st = (hipStream_t)stream;
@@ -261,16 +261,21 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     aa.ntiles = ntiles_of(aa.tm);
     const int nc = nchunk < aa.ntiles ? nchunk : aa.ntiles;
     float* slab_ln1 = slab_attn + (long)nc * heads * MSST_ATTN_SLAB_N;
+    // saved LN1 rows + pre-dropped bf16 da rows: both or neither, and only for the tuned bf16 attention kernel
+    const char* dbg_env = getenv("MSST_DBG");
+    const bool fast_rows = xn_saved && dab_ws && prec == MSST_PREC_BF16 && !((dbg_env ? atoi(dbg_env) : 0) & 16);
     // 1. MLP half: dy -> dx1
     {
         MlpBwdArgs a;
         a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok; a.drop = drop;
+        a.dab = fast_rows ? dab_ws : nullptr;
         int rc = launch_block_bwd_mlp(a, grid_mlp, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
     }
     // 2. attention half, per (chunk, head)
     {
-        aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn; aa.xn = xn_saved;
+        aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
+        aa.xn = fast_rows ? xn_saved : nullptr; aa.dab = fast_rows ? dab_ws : nullptr;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
         { const char* e = getenv("MSST_DBG"); aa.dbg = e ? atoi(e) : 0; }
         aa.stamps = g_stamps;

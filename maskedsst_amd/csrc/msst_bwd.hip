@@ -323,6 +323,13 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o4[r] = dyv[mt][r] + rstd * (dxn[mt][r] - g1 - xhat[mt][r] * g2);
                 *reinterpret_cast<f32x4*>(a.dx1 + tok * 96 + m0) = o4;
+                if constexpr (sizeof(elem) == 2) {
+                    if (a.dab) {   // the attention half's operand: same rows, to_out dropout (site 2) applied, bf16
+                        f32x4 d4 = o4;
+                        if (a.drop.thr) d4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), d4);
+                        *reinterpret_cast<s16x4*>(reinterpret_cast<bf16_t*>(a.dab) + tok * 96 + m0) = f2bf4(d4);
+                    }
+                }
             }
         }
         lds_barrier();

@@ -106,7 +106,8 @@ __device__ __forceinline__ void da_pack(const f32x4 (&dav)[6], const Drop& drop,
 }  // namespace
 
 // DROP: dropout compiled in / out (uniform run-time tests would split the instruction stream into basic blocks)
-// XN: the forward saved LN1(x) as bf16 rows (a.xn): they are loaded straight into the packed registers, x is never read
+// XN: the forward saved LN1(x) as bf16 rows (a.xn) and the MLP half left the dropped bf16 da rows (a.dab): both are loaded
+// straight into the packed registers; x / da are never read, nothing is normalised, hashed or converted here
 template <bool DROP, bool XN>
 __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs a) {
     typedef Bwd2Smem SM;
@@ -158,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         for (int i = 0; i < 6; ++i) dst[i] = src[i];
     };
 
-    auto load_xn = [&](long tok, s16x4 (&dst)[6]) {   // 48 bytes of the thread's bf16 row slice, clamped address
-        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const elem*>(a.xn) + (tok >= 0 ? tok : 0) * 96 + (launder(tid) & 3) * 24);
+    auto load_bf = [&](const void* base, long tok, s16x4 (&dst)[6]) {   // 48 bytes of the thread's bf16 row slice, clamped address
+        const u32x4* src = reinterpret_cast<const u32x4*>(reinterpret_cast<const elem*>(base) + (tok >= 0 ? tok : 0) * 96 + (launder(tid) & 3) * 24);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const u32x4 v = src[i];
@@ -176,10 +177,10 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
     {
         const long tok0 = tok_of(blockIdx.x);
         f32x4 xv[6], dav[6];
-        if constexpr (XN) load_xn(tok0, xnk); else load_rows(a.x, tok0, xv);
-        load_rows(a.da, tok0, dav);
+        if constexpr (XN) load_bf(a.xn, tok0, xnk); else load_rows(a.x, tok0, xv);
+        if constexpr (XN) load_bf(a.dab, tok0, dak); else load_rows(a.da, tok0, dav);
         if constexpr (XN) {
-            if (tok0 < 0) zero_xn(xnk);
+            if (tok0 < 0) { zero_xn(xnk); zero_xn(dak); }
         } else {
             if (tok0 < 0) {
 #pragma unroll
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             }
             ln_pack(xv, lnp, tid & 3, xnk);
         }
-        da_pack<DROP>(dav, a.drop, tok0, tid & 3, dak);
+        if constexpr (!XN) da_pack<DROP>(dav, a.drop, tok0, tid & 3, dak);
     }
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -494,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         }
         // rows of the NEXT tile of this workgroup: requested now, normalised between the two phase-D GEMMs
         f32x4 xv[6];
-        if constexpr (XN) load_xn(tok_of(tile + gridDim.x), xnk);   // the restore above was the last use of this tile's rows
+        if constexpr (XN) load_bf(a.xn, tok_of(tile + gridDim.x), xnk);   // the restore above was the last use of this tile's rows
         else load_rows(a.x, tok_of(tile + gridDim.x), xv);
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
         {
@@ -523,7 +524,8 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         lds_barrier();
         STAMP(14);    // every wave is done reading xd (weight-grad GEMM above); staged weights visible
         f32x4 dav[6];   // da rows of the next tile: requested under the d(LN1 out) GEMM, packed after the copy-out
-        load_rows(a.da, tok_of(tile + gridDim.x), dav);
+        if constexpr (XN) load_bf(a.dab, tok_of(tile + gridDim.x), dak);   // this tile's copy went to xd at the head of phase B
+        else load_rows(a.da, tok_of(tile + gridDim.x), dav);
         {
             // dxn_h[row][m] = sum_d dq Wq + dk Wk + dv Wv         C[i = m tile][j = row tile wave]
             f32x4 dx[6];
@@ -577,7 +579,9 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             // the next iteration, the wait crosses the loop edge, becomes vmcnt(0) and also waits for the stores above
 #pragma unroll
             for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(xnk[i]));
-            if (tok_of(tile + gridDim.x) < 0) zero_xn(xnk);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(dak[i]));
+            if (tok_of(tile + gridDim.x) < 0) { zero_xn(xnk); zero_xn(dak); }   // padding rows must carry zero da
         } else {
             if (tok_of(tile + gridDim.x) < 0) {
 #pragma unroll
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
             }
             ln_pack(xv, lnp, launder(tid) & 3, xnk);
         }
-        da_pack<DROP>(dav, a.drop, tok_of(tile + gridDim.x), launder(tid) & 3, dak);
+        if constexpr (!XN) da_pack<DROP>(dav, a.drop, tok_of(tile + gridDim.x), launder(tid) & 3, dak);
         STAMP(16);
         // no block barrier here: the next tile's first stores only touch this wave's own xd rows, and q / k / vt
         // are not written before the barrier that follows them
@@ -621,7 +625,7 @@ int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st)
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.xn ? 2 : 0)], dim3(nchunk, a.H), dim3(256), smem, st, a);
+    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + ((a.xn && a.dab) ? 2 : 0)], dim3(nchunk, a.H), dim3(256), smem, st, a);
     return (int)hipGetLastError();
 }
 

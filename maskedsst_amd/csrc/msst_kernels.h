@@ -80,6 +80,7 @@ struct HeadBwdArgs {
 struct MlpBwdArgs {
     BlockWeights w;
     const float* x1; const float* dy; float* dx1; float* slab;
+    void* dab;   // optional [tokens][96] bf16: dx1 with the to_out dropout (site 2) applied, packed -- what the bf16 attention backward feeds its MFMAs
     long ntok;
     Drop drop;
 };
@@ -87,6 +88,7 @@ struct MlpBwdArgs {
 struct AttnBwdArgs {
     BlockWeights w;
     const float* x; const float* da; void* dxn_part; float* slab;
+    const void* dab;  // optional [tokens][96] bf16 pre-dropped da rows written by the MLP half (given together with xn)
     const void* xn;   // optional [tokens][96] bf16 LN1(x) saved by the forward: the bf16 kernel then neither re-reads x nor renormalises
     TileMap tm;
     int ntiles, H;

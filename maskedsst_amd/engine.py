@@ -248,6 +248,7 @@ class Engine:
         esz = 4 if self.prec == PREC_F32 else 2
         dx1 = torch.empty(ntok * 96, dtype=torch.float32, device=dev)
         part = torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev)
+        dab = torch.empty(ntok * 96, dtype=torch.bfloat16, device=dev) if self.prec != PREC_F32 else None
         # the bf16 MLP backward runs two workgroups per CU: up to 2 * grid_rows MLP slabs (msst_block_bwd lays the parts out)
         nslab = self.grid_rows * (2 * MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
         slab = torch.empty(nslab, dtype=torch.float32, device=dev)
@@ -260,7 +261,7 @@ class Engine:
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec,
-                drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _stream()), "msst_block_bwd")
+                drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g

@@ -104,21 +104,23 @@ def test_param_grads_bf16(cfg):
     assert not bad, bad
 
 
+@pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
 @pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_attn_bwd_kernels_agree(cfg, monkeypatch):
-    """The tuned bf16 attention backward (msst_bwd2.hip) against the template kernel it was derived from
-    (msst_bwd.hip, MSST_DBG=16): same bf16 operands, same dropout-free arithmetic up to summation order, so every
-    gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and spectral tiles, 64- and
-    short-sequence masking, padding rows)."""
+def test_attn_bwd_kernels_agree(cfg, drop, monkeypatch):
+    """The tuned bf16 attention backward (msst_bwd2.hip; fed with the LN1 rows saved by the forward and the pre-dropped
+    bf16 da rows left by the MLP half) against the template kernel it was derived from (msst_bwd.hip, MSST_DBG=16;
+    re-reads x / dx1, renormalises, applies the to_out dropout itself): same bf16 operands and the same dropout masks up
+    to summation order, so every gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and
+    spectral tiles, 64- and short-sequence masking, padding rows, with and without dropout)."""
     model, params, x = build_product(cfg, precision="bf16", device="cuda")
     eng = model.engine()
     masks = model.draw_masks(cfg["B"])
-    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
     dy = torch.randn_like(out["enc_out"]) * 1e-3
 
     def run():
-        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone())
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=drop)
         torch.cuda.synchronize()
         return dx0.clone(), eng.fp.grad.clone()
 
