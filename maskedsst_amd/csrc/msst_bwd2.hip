@@ -400,6 +400,15 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         lds_barrier();
         STAMP(8);
         B2_PRIO(1);
+        // XN: the NEXT tile's saved rows are requested here, four GEMM phases (~5 k cycles) before they are needed: a row
+        // request takes 2-3 k cycles under load.  This tile's da rows went to xd at the head of phase B (dak is free); its
+        // LN1 rows are still needed for the restore after C2, so the next ones land in a second register set
+        s16x4 xnn[6];
+        if constexpr (XN) {
+            const long tokn = tok_of(tile + gridDim.x);
+            load_bf(a.xn, tokn, xnn);
+            load_bf(a.dab, tokn, dak);
+        }
         // ---------------- phase C: contractions over all 64 queries / keys ----------------
         // C1: dWout_h and dv (reads xd = da, o, p, dO); dv -> vt (dead since phase B)
         {
@@ -495,8 +504,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         }
         // rows of the NEXT tile of this workgroup: requested now, normalised between the two phase-D GEMMs
         f32x4 xv[6];
-        if constexpr (XN) load_bf(a.xn, tok_of(tile + gridDim.x), xnk);   // the restore above was the last use of this tile's rows
-        else load_rows(a.x, tok_of(tile + gridDim.x), xv);
+        if constexpr (!XN) load_rows(a.x, tok_of(tile + gridDim.x), xv);
         // ---------------- phase D: qkv weight grads and the head's d(LN1 out) partial ----------------
         {
             // dW{q,k,v}[d][m] += sum_row d{q,k,v}[row][d] xn[row][m]    C[i = d tile wave][j = m tile t]
@@ -520,12 +528,12 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
                 });
         }
         STAMP(13);
-        wait_vm0();   // this wave's staged fragments have landed
+        // this wave's staged fragments have landed
+        wait_vm0();
         lds_barrier();
         STAMP(14);    // every wave is done reading xd (weight-grad GEMM above); staged weights visible
         f32x4 dav[6];   // da rows of the next tile: requested under the d(LN1 out) GEMM, packed after the copy-out
-        if constexpr (XN) load_bf(a.dab, tok_of(tile + gridDim.x), dak);   // this tile's copy went to xd at the head of phase B
-        else load_rows(a.da, tok_of(tile + gridDim.x), dav);
+        if constexpr (!XN) load_rows(a.da, tok_of(tile + gridDim.x), dav);
         {
             // dxn_h[row][m] = sum_d dq Wq + dk Wk + dv Wv         C[i = m tile][j = row tile wave]
             f32x4 dx[6];
@@ -553,6 +561,18 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
                     for (int j = 0; j < 3; ++j) dx[3 * half + j] = P::mma(fw[s % 3][j], fb[ks][which], dx[3 * half + j]);
                 });
             STAMP(15);
+            if constexpr (XN) {
+                // pin the arrival of the next tile's saved rows HERE, before the copy-out stores are issued: a wait placed after
+                // them (or left to the store at the top of the next iteration, across the loop edge) becomes vmcnt(0) and
+                // sits out the acknowledgement of those stores -- 1.3 k cycles per tile
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(xnn[i]));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(dak[i]));
+#pragma unroll
+                for (int i = 0; i < 6; ++i) xnk[i] = xnn[i];   // this tile's LN1 rows were last used by the restore after C2
+                if (tok_of(tile + gridDim.x) < 0) { zero_xn(xnk); zero_xn(dak); }   // padding rows must carry zero da
+            }
             // stage the [16 x 96] result rows of this wave in xd (dead now) and write whole rows
 #pragma unroll
             for (int t = 0; t < 6; ++t) P::st_nat(&sm.xd[wave * 16][t * 16], LDX, dx[t]);
@@ -575,13 +595,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
         }
         // LN1 of the next tile's rows (requested before the weight-grad GEMM); padding rows normalise zeros
         if constexpr (XN) {
-            // pin the arrival of the saved rows HERE (a counted vmcnt in straight-line code): left to the store at the top of
-            // the next iteration, the wait crosses the loop edge, becomes vmcnt(0) and also waits for the stores above
-#pragma unroll
-            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(xnk[i]));
-#pragma unroll
-            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(dak[i]));
-            if (tok_of(tile + gridDim.x) < 0) { zero_xn(xnk); zero_xn(dak); }   // padding rows must carry zero da
+            // (the saved rows were pinned before the copy-out, see above)
         } else {
             if (tok_of(tile + gridDim.x) < 0) {
 #pragma unroll
