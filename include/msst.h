@@ -11,8 +11,9 @@
  * Rules: plain pointers and sizes only (no torch types); every pointer is DEVICE memory owned by
  * the caller unless marked "host"; calls only enqueue work on `stream` (a hipStream_t passed as
  * void*), never synchronise, never allocate; returns 0 or a negative MSST_ERR_* / positive
- * hipError_t code, never throws; re-entrant (no mutable global state besides a thread-local error
- * string).  All activations are fp32 [tokens][96] in the reference token order 'b (c h w) d'.
+ * hipError_t code, never throws; re-entrant: the compute entry points keep no state between calls and
+ * read no environment (a thread-local error string; idempotent once-flags for kernel attributes; the
+ * opt-in msst_profile_* state is mutex-guarded and, when disabled, costs one relaxed atomic load).  All activations are fp32 [tokens][96] in the reference token order 'b (c h w) d'.
  * The kernels are specialised for dim = 96, dim_head = 64, mlp_dim = 64 (configs/config.yaml:19-22
  * of the reference); heads, depth, bands, batch are runtime.
  */
@@ -31,6 +32,12 @@ extern "C" {
 
 #define MSST_PREC_F32 0  /* exact fp32 MFMA (parity mode)               */
 #define MSST_PREC_BF16 1 /* bf16 MFMA operands, fp32 accumulate/residual */
+
+/* Kernel-selection flags, OR-ed into the `prec` argument of msst_block_fwd / msst_block_bwd (bits 8..23).  0 selects the
+ * tuned kernels; the others exist for the cross-kernel agreement tests and A/B studies.  They are explicit arguments:
+ * the library never reads the environment and keeps no per-call state. */
+#define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
+#define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
 
 #define MSST_MODE_SPATIAL 0  /* sequences = (b, c), N tokens each, contiguous            */
 #define MSST_MODE_SPECTRAL 1 /* sequences = (b, n), S tokens each, stride N*96 floats    */
@@ -166,7 +173,8 @@ int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
 /* Opt-in per-kernel timing: when enabled every kernel launch of the library is bracketed by a pair
  * of HIP events recorded on the launch stream.  msst_profile_collect synchronises on the recorded
  * events and returns, per kernel id (0 .. msst_profile_kernels()-1), the summed duration in ms and
- * the launch count since enable / the previous collect.  Not thread-safe; meant for bench.py. */
+ * the launch count since enable / the previous collect.  Thread-safe (mutex); meant for bench.py.
+ * msst_debug_stamps: kernel-study builds (-DMSST_STAMPS) only; returns MSST_ERR_UNSUPPORTED otherwise. */
 int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tools/stamps.py */);
 int msst_profile_enable(int on);
 /* restrict the event pairs to the kernel ids whose bit is set (default: all); each pair costs ~10 us of stream time */

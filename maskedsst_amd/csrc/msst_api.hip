@@ -4,6 +4,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <mutex>
 #include <vector>
 
 namespace msst {
@@ -48,14 +50,20 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
 // ------------------------------------------------------------------------------------------
 // opt-in profiler: a pair of HIP events around each kernel launch, on the launch stream
 // ------------------------------------------------------------------------------------------
+// The compute entry points keep no state: with the profiler off (the default) a call reads ONE relaxed atomic flag
+// and nothing else that is shared.  The opt-in profiler state below is guarded by a mutex (records) and is
+// per-thread where a launch is bracketed (the open record), so enabling it never makes a compute call unsafe.
 struct ProfRec { int id; hipEvent_t a, b; };
-static unsigned long long* g_stamps = nullptr;
-static bool g_prof_on = false;
-static unsigned long long g_prof_mask = ~0ull;   // kernels (bit = id) that get event pairs
+#ifdef MSST_STAMPS
+static unsigned long long* g_stamps = nullptr;   // kernel-study builds only (python -m maskedsst_amd.build --stamps)
+#endif
+static std::atomic<bool> g_prof_on{false};
+static std::atomic<unsigned long long> g_prof_mask{~0ull};   // kernels (bit = id) that get event pairs
+static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
 static size_t g_pool_next = 0;
-static ProfRec* g_open = nullptr;
+static thread_local hipEvent_t g_open_end = nullptr;   // end event of the launch this thread is bracketing
 
 static hipEvent_t pool_event() {
     if (g_pool_next == g_pool.size()) {
@@ -67,17 +75,21 @@ static hipEvent_t pool_event() {
 }
 
 void prof_begin(int id, hipStream_t st) {
-    if (!g_prof_on || !((g_prof_mask >> id) & 1ull)) return;
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    if (!((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1ull)) return;
     ProfRec r;
-    r.id = id; r.a = pool_event(); r.b = pool_event();
+    {
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        r.id = id; r.a = pool_event(); r.b = pool_event();
+        g_prof.push_back(r);
+    }
     hipEventRecord(r.a, st);
-    g_prof.push_back(r);
-    g_open = &g_prof.back();
+    g_open_end = r.b;
 }
 void prof_end(hipStream_t st) {
-    if (!g_prof_on || !g_open) return;
-    hipEventRecord(g_open->b, st);
-    g_open = nullptr;
+    if (!g_open_end) return;
+    hipEventRecord(g_open_end, st);
+    g_open_end = nullptr;
 }
 
 static TileMap make_tilemap(int mode, int B, int S, int N) {
@@ -126,15 +138,24 @@ extern "C" {
 int msst_version(void) { return MSST_VERSION; }
 const char* msst_last_error(void) { return g_err; }
 
-int msst_debug_stamps(void* buf) { g_stamps = (unsigned long long*)buf; return 0; }
+int msst_debug_stamps(void* buf) {
+#ifdef MSST_STAMPS
+    g_stamps = (unsigned long long*)buf;
+    return 0;
+#else
+    (void)buf;
+    return fail(MSST_ERR_UNSUPPORTED, "msst_debug_stamps (library built without -DMSST_STAMPS)");
+#endif
+}
 
 int msst_profile_enable(int on) {
-    g_prof_on = on != 0;
-    if (on) { g_prof.clear(); g_pool_next = 0; g_open = nullptr; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (on) { g_prof.clear(); g_pool_next = 0; }
+    g_prof_on.store(on != 0);
     return 0;
 }
 
-int msst_profile_select(unsigned long long mask) { g_prof_mask = mask; return 0; }
+int msst_profile_select(unsigned long long mask) { g_prof_mask.store(mask); return 0; }
 
 int msst_profile_kernels(void) { return K_COUNT; }
 
@@ -146,6 +167,7 @@ const char* msst_profile_name(int id) {
 }
 
 int msst_profile_collect(double* total_ms, long* count) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < K_COUNT; ++i) { total_ms[i] = 0.0; count[i] = 0; }
     for (const ProfRec& r : g_prof) {
         if (hipEventSynchronize(r.b) != hipSuccess) return fail(MSST_ERR_BADARG, "msst_profile_collect");
@@ -188,6 +210,8 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
                    void* xn_out, int* xn_written, void* stream) {
     if (!w || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (sequence length > 64)");
+    const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
+    prec &= 0xff;
     BlockArgs a;
     a.w = to_bw(w);
     a.x = x; a.y = y; a.x1 = x1;
@@ -196,9 +220,12 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.max_grid = max_grid > 0 ? max_grid : a.ntiles;
     a.H = heads;
     a.scale = 0.125f;  // dim_head ** -0.5, dim_head = 64 (vit_spatial_spectral.py:54)
-    { const char* e = getenv("MSST_DBG"); a.dbg = e ? atoi(e) : 0; }
+    a.dbg = dbg & ~8;
+    a.stamps = nullptr;
+#ifdef MSST_STAMPS
     a.stamps = g_stamps;
-    if (!g_stamps) a.dbg &= ~8;
+    if (g_stamps) a.dbg = dbg;
+#endif
     a.drop = make_drop(dropout_p, seed, layer);
     a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
     if (xn_written) *xn_written = a.xn_out ? 1 : 0;
@@ -226,15 +253,22 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
     if (rc) return fail(rc, "msst_head_bwd");
     const long ss = (long)P * 96 + P;
     RSegBuilder rb;
+    bool ok = true;
     if (per_block) {
-        for (int c = 0; c < S; ++c) {
-            rb.add(slab + (long)c * nchunk * ss, ss, nchunk, dw_pix + (long)c * P * 96, P * 96);
-            rb.add(slab + (long)c * nchunk * ss + P * 96, ss, nchunk, db_pix + (long)c * P, P);
+        for (int c = 0; c < S && ok; ++c) {
+            ok = rb.add(slab + (long)c * nchunk * ss, ss, nchunk, dw_pix + (long)c * P * 96, P * 96);
+            ok = ok && rb.add(slab + (long)c * nchunk * ss + P * 96, ss, nchunk, db_pix + (long)c * P, P);
+            if (rb.r.nseg > MSST_MAX_RSEG - 2 && c + 1 < S) {   // table full (S > 36): flush and start a new one
+                rc = launch_reduce_segs(rb.r, st);
+                if (rc) return fail(rc, "msst_head_bwd(reduce)");
+                rb = RSegBuilder();
+            }
         }
     } else {
-        rb.add(slab, ss, S * nchunk, dw_pix, P * 96);
-        rb.add(slab + P * 96, ss, S * nchunk, db_pix, P);
+        ok = rb.add(slab, ss, S * nchunk, dw_pix, P * 96);
+        ok = ok && rb.add(slab + P * 96, ss, S * nchunk, db_pix, P);
     }
+    if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_head_bwd(reduce table)");
     rc = launch_reduce_segs(rb.r, st);
     return fail(rc, "msst_head_bwd(reduce)");
 }
@@ -246,6 +280,8 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
     hipStream_t st = (hipStream_t)stream;
+    const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
+    prec &= 0xff;
     const long ntok = (long)B * S * N;
     const BlockWeights bw = to_bw(w);
     const Drop drop = make_drop(dropout_p, seed, layer);
@@ -262,8 +298,7 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     const int nc = nchunk < aa.ntiles ? nchunk : aa.ntiles;
     float* slab_ln1 = slab_attn + (long)nc * heads * MSST_ATTN_SLAB_N;
     // saved LN1 rows + pre-dropped bf16 da rows: both or neither, and only for the tuned bf16 attention kernel
-    const char* dbg_env = getenv("MSST_DBG");
-    const bool fast_rows = xn_saved && dab_ws && prec == MSST_PREC_BF16 && !((dbg_env ? atoi(dbg_env) : 0) & 16);
+    const bool fast_rows = xn_saved && dab_ws && prec == MSST_PREC_BF16 && !(dbg & 16);
     // 1. MLP half: dy -> dx1
     {
         MlpBwdArgs a;
@@ -277,9 +312,12 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
         aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
         aa.xn = fast_rows ? xn_saved : nullptr; aa.dab = fast_rows ? dab_ws : nullptr;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
-        { const char* e = getenv("MSST_DBG"); aa.dbg = e ? atoi(e) : 0; }
+        aa.dbg = dbg & ~8;
+        aa.stamps = nullptr;
+#ifdef MSST_STAMPS
         aa.stamps = g_stamps;
-        if (!g_stamps) aa.dbg &= ~8;
+        if (g_stamps) aa.dbg = dbg;
+#endif
         int rc = launch_block_bwd_attn(aa, nc, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(attn)");
     }
@@ -346,7 +384,7 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
     bool ok = true;
     for (int c = 0; c < S && ok; ++c) {   // per spectral block: position rows, embed weight, embed bias
         const float* sc = slab + c * bs;
-        ok = rb.add(sc, ss, nchunk, dpos_dst + (long)c * N * 96, N * 96);
+        if (dpos_a) ok = rb.add(sc, ss, nchunk, dpos_dst + (long)c * N * 96, N * 96);   // null: position table applied by the caller
         ok = ok && rb.add(sc + N * 96, ss, nchunk, dw_emb + (long)c * 96 * P, 96 * P);
         ok = ok && rb.add(sc + v0, ss, nchunk, db_emb + (long)c * 96, 96);
         if (rb.r.nseg > MSST_MAX_RSEG - 8) {
@@ -363,7 +401,7 @@ int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, 
     ok = ok && rb.add(slab + v0 + 384 + 16, ss, S * nchunk, dpre_b, P);
     if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_tokenize_bwd(reduce table)");
     rc = launch_reduce_segs(rb.r, st);
-    if (!rc && pos_split) rc = launch_pos_split(stage, S, N, pos_split, dpos_a, dpos_b, st);
+    if (!rc && pos_split && dpos_a) rc = launch_pos_split(stage, S, N, pos_split, dpos_a, dpos_b, st);
     return fail(rc, "msst_tokenize_bwd(reduce)");
 }
 

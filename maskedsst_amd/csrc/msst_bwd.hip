@@ -8,6 +8,7 @@
 //   block_bwd_ln1   sum of the per-head d(LN1 out) partials, LN1 backward, residual
 //   tokenize_bwd    grads of the patch embedding, its two LayerNorms, position table and mask token
 //   reduce_slabs    deterministic reduction of the per-workgroup partial-gradient slabs
+#include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 
@@ -1327,7 +1328,7 @@ int launch_reduce_segs(const RSegs& r, hipStream_t st) {
 }
 
 template <class K>
-static int set_smem(K kernel, size_t smem, bool& done) {
+static int set_smem(K kernel, size_t smem, std::atomic<bool>& done) {
     if (!done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1338,7 +1339,7 @@ static int set_smem(K kernel, size_t smem, bool& done) {
 }
 
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st) {
-    static bool d0 = false, d1 = false;
+    static std::atomic<bool> d0{false}, d1{false};
     if (prec == MSST_PREC_F32) {
         const size_t smem = sizeof(MlpBwdSmem<PF32>) + 256 * sizeof(float);
         int rc = set_smem(&block_bwd_mlp_kernel<PF32>, smem, d0);
@@ -1356,7 +1357,7 @@ int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st
 }
 
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st) {
-    static bool d0 = false, d1 = false;
+    static std::atomic<bool> d0{false}, d1{false};
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     dim3 grid(nchunk, a.H);
     if (prec == MSST_PREC_F32) {

@@ -16,6 +16,7 @@
 //     tile-start value stays live (= spilled) across the register-hungry phases.
 // grid (nchunk, H): workgroup (chunk, h) walks the 64-row tiles chunk, chunk + nchunk, ... for ONE head and keeps
 // the head's weight gradients (dWq | dWk | dWv [3][64][96], dWout_h [96][64]) in 96 registers per lane.
+#include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 
@@ -624,7 +625,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_bf16_kernel(AttnBwdArgs
 }
 
 int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
     const size_t smem = sizeof(Bwd2Smem) + 192 * sizeof(float);
     typedef void (*kern_t)(AttnBwdArgs);

@@ -6,6 +6,7 @@
 //   head_fwd       a12-a14      gather masked tokens -> per-spectral-block Linear(96->P) -> masked L1
 //
 // Reference semantics (file:line under the reference repo) are cited at each kernel.
+#include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 
@@ -737,7 +738,7 @@ int launch_tokenize_fwd(const TokArgs& a, hipStream_t st) {
 
 template <class P>
 static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t smem = sizeof(FwdSmem<P>);
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_kernel<P>),
@@ -751,7 +752,7 @@ static int launch_block_fwd_t(const BlockArgs& a, int grid, hipStream_t st) {
 }
 
 static int launch_block_fwd_bf16(const BlockArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t smem = sizeof(FwdSmem<PBF16>) + 640 * sizeof(float) + 24 * 1024;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_bf16_kernel),
@@ -772,11 +773,13 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
         return prec == MSST_PREC_F32 ? launch_block_fwd_t<PF32>(a, grid, st) : launch_block_fwd_t<PBF16>(a, grid, st);
     }
     if (a.H == 8 && !(a.dbg & 64)) {   // head-per-wave kernel: one 512-thread workgroup per CU walks the tiles
-        static int ncu = 0;
+        static std::atomic<int> ncu_cached{0};   // idempotent once-value (every gfx950 part this library targets has the same count per process)
+        int ncu = ncu_cached.load(std::memory_order_relaxed);
         if (!ncu) {
             int dev = 0;
             hipGetDevice(&dev);
             if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+            ncu_cached.store(ncu, std::memory_order_relaxed);
         }
         int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
         if (grid > ncu) grid = ncu;

@@ -20,6 +20,7 @@
 //     the other feature half through 2 floats per row) and the MLP residual never touch LDS.  (The first version
 //     summed eight fp32 per-head partials through LDS: 288 four-byte LDS operations per wave and a row-wise
 //     re-read -- 44 % of the tile time.)
+#include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 #include <type_traits>
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 }
 
 int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     const size_t smem = sizeof(Fwd2Smem) + 640 * sizeof(float) + 24 * 1024;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_hw_kernel<false>),

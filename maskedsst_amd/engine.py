@@ -29,6 +29,13 @@ def _prec_of(name):
     raise ValueError(f"unknown precision {name!r} (use 'bf16' or 'fp32')")
 
 
+def _kernel_flags():
+    """MSST_KERNEL_* selection flags (include/msst.h), read from the environment on the HOST side per call: the
+    library itself never reads the environment.  MSST_DBG=16 selects the generic template kernels, 64 the 4-wave
+    forward; 0 (default) the tuned kernels."""
+    return (int(os.environ.get("MSST_DBG", "0")) & 0xffff) << 8
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -186,7 +193,7 @@ class Engine:
             wrote = ctypes.c_int(0)
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
             _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec, self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
+                                               self.prec | _kernel_flags(), self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
                                                _stream()),
                        "msst_block_fwd")
             if x1 is not None:
@@ -260,13 +267,16 @@ class Engine:
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
-                _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec,
+                _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
+                self.prec | _kernel_flags(),
                 drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g
 
-    def tokenize_bwd(self, img, mask_u8, dx0, emb_drop=(0.0, 0)):
+    def tokenize_bwd(self, img, mask_u8, dx0, emb_drop=(0.0, 0), with_pos=True):
+        """with_pos=False: gradients of the embedding / its two LayerNorms only (the position table and the mask
+        token were applied outside the kernel, by the caller's own autograd ops)"""
         B = img.shape[0]
         S, N, P = self.S, self.N, self.P
         dev = img.device
@@ -275,20 +285,23 @@ class Engine:
         slab = torch.empty(S * nchunk * ss + S * N * 96, dtype=torch.float32, device=dev)
         fp, g = self.fp, self.fp.grad
         V = ctypes.c_void_p
-        if self.enc.spectral_pos_embed:
+        if not with_pos:
+            split, dpa, dpb = 0, 0, 0
+        elif self.enc.spectral_pos_embed:
             split = self.enc.pos_embed.shape[-1]
             dpa, dpb = fp.ptr("pos_embed", g), fp.ptr("channel_embed", g)
         else:
             split = 0
             dpa, dpb = fp.ptr("pos_embedding", g), 0
-        dmt = fp.ptr("mask_token", g) if self.mim is not None else 0
+        dmt = fp.ptr("mask_token", g) if (self.mim is not None and with_pos) else 0
         _lib.check(self.lib.msst_tokenize_bwd(
             _p(img), V(fp.ptr("pre_g")), V(fp.ptr("pre_b")), V(fp.ptr("embed.w.0")), V(fp.ptr("embed.b.0")),
             V(fp.ptr("post_g")), V(fp.ptr("post_b")), _p(mask_u8), _p(dx0), _p(slab), nchunk,
             V(fp.ptr("pre_g", g)), V(fp.ptr("pre_b", g)), V(fp.ptr("embed.w.0", g)), V(fp.ptr("embed.b.0", g)),
             V(fp.ptr("post_g", g)), V(fp.ptr("post_b", g)), V(dpa), V(dpb), split, V(dmt), B, S, N, P,
             emb_drop[0], emb_drop[1], _stream()), "msst_tokenize_bwd")
-        self._fire("tokenizer")
+        if with_pos:
+            self._fire("tokenizer")
 
     # ------------------------------------------------------------------ autograd entry (SimMIM loss)
     def trainable(self):
@@ -306,7 +319,13 @@ class Engine:
             return 0.0, 0
         if not 0.0 < p < 1.0:
             raise ValueError(f"dropout probability {p} outside (0, 1)")
-        return p, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        # data parallel: every rank draws the same seed from identically seeded generators; mix the rank in so that
+        # the ranks' dropout masks are independent (as they are for the reference's per-process RNG streams)
+        rank = int(getattr(self.mim, "dp_rank", 0)) if self.mim is not None else 0
+        if rank:
+            seed = (seed ^ (rank * 0x9E3779B1)) & 0x7FFFFFFF
+        return p, seed
 
     def _upload(self, dev, *arrays):
         """Host arrays of one step -> device, without stalling the launch queue.
@@ -316,7 +335,9 @@ class Engine:
         2 ms per 41 ms step).  Going through pinned staging buffers keeps the copies asynchronous: they queue on
         the compute stream behind the previous step and the host keeps launching.  Two pinned sets alternate; a
         set is rewritten only after the copy that last read it has run (host waits on its event, i.e. the host
-        runs at most two steps ahead)."""
+        runs at most two steps ahead).  The DEVICE tensors are fresh per call (caching allocator, stream ordered):
+        the autograd path stashes them for its backward, and any number of further forwards (eval / no_grad ones
+        included) may run between a forward and its backward without touching them."""
         if getattr(self, "_up", None) is None:
             self._up = {"sets": [None, None], "k": 0}
         up = self._up
@@ -327,17 +348,18 @@ class Engine:
         if cur is None or cur["sig"] != sig:
             cur = {"sig": sig,
                    "pin": [torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, pin_memory=True) for a in arrays],
-                   "dev": [torch.empty(a.shape, dtype=torch.from_numpy(a).dtype, device=dev) for a in arrays],
                    "ev": torch.cuda.Event()}
             up["sets"][k] = cur
         else:
             cur["ev"].synchronize()
+        out = []
         for pin, a in zip(cur["pin"], arrays):
             pin.numpy()[...] = a
-        for d, pin in zip(cur["dev"], cur["pin"]):
+            d = torch.empty(pin.shape, dtype=pin.dtype, device=dev)
             d.copy_(pin, non_blocking=True)
+            out.append(d)
         cur["ev"].record(torch.cuda.current_stream(dev))
-        return cur["dev"]
+        return out
 
     def simmim_loss(self, img, bool_mask, idx):
         """scalar loss attached to autograd (reference SimMIMSpatialSpectral.forward :203-340)"""
@@ -362,27 +384,51 @@ class Engine:
         return _SimMIMLossFn.apply(self, names, self.dropout_state(), img, mask_u8, idx32, csr_ptr, csr_pos, *params)
 
     # ------------------------------------------------------------------ encoder-level API (inference)
+    def _block_param_names(self):
+        return [n for n, _ in self.trainable() if n.startswith(("spatial.", "spectral."))]
+
+    def _embed_param_names(self):
+        return [n for n, _ in self.trainable() if n.startswith(("embed.", "pre_", "post_"))]
+
     def transformer(self, tokens):
-        """ViTSpatialSpectral.transformer_forward: both stacks on [B, T, 96] tokens (forward only)."""
+        """ViTSpatialSpectral.transformer_forward (reference :495-499): both stacks on [B, T, 96] tokens.  Attached to
+        autograd when gradients are enabled, so a caller that keeps the reference's own SimMIMSpatialSpectral
+        (vit_simmim_original.py:298) and swaps only the encoder trains through the HIP blocks: d(tokens) flows on to
+        whatever produced them, the block parameters receive views of the flat gradient buffer."""
         self._require_cuda(tokens)
-        if torch.is_grad_enabled() and tokens.requires_grad:
-            raise NotImplementedError("autograd through transformer_forward alone is not wired up yet; "
-                                      "train through SimMIMSpatialSpectral")
+        self.ensure()
+        drop = self.dropout_state()
+        tokens = tokens.contiguous().float()
+        by_name = dict(self.trainable())
+        names = self._block_param_names()
+        params = [by_name[n] for n in names]
+        if torch.is_grad_enabled() and (tokens.requires_grad or any(p.requires_grad for p in params)):
+            return _TransformerFn.apply(self, names, drop, tokens, *params)
         self.prep_weights()
-        acts, _ = self.blocks_fwd(tokens.contiguous().float(), save=False)
+        acts, _ = self.blocks_fwd(tokens, save=False, drop=drop)
         return acts[-1]
 
     def embed_patches(self, patches):
-        """BlockwisePatchEmbedding.embed on patches [B, S, N, P] (no position / mask terms)."""
+        """BlockwisePatchEmbedding.embed on patches [B, S, N, P] (no position / mask terms; reference :210-222),
+        attached to autograd for the embedding parameters when gradients are enabled."""
         self._require_cuda(patches)
+        self.ensure()
         B, S, N, P = patches.shape
-        img = patches.permute(0, 1, 3, 2).reshape(B, S * P, N).contiguous()
+        img = patches.detach().permute(0, 1, 3, 2).reshape(B, S * P, N).contiguous().float()
+        by_name = dict(self.trainable())
+        names = self._embed_param_names()
+        params = [by_name[n] for n in names]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            return _EmbedFn.apply(self, names, img, *params)
         return self.tokenize(img, None, with_pos=False)
 
     def features(self, img):
-        """forward_features (eval): tokenize + pos -> transformer"""
-        x0 = self.tokenize(img, None, with_pos=True)
-        return self.transformer(x0)
+        """forward_features (reference :518-534): tokenize + pos (+ embedding dropout in training mode) -> transformer"""
+        pe = float(self.enc.emb_dropout_p) if self.enc.training else 0.0
+        emb_drop = (pe, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if pe > 0 else (0.0, 0)
+        x0 = self.tokenize(img, None, with_pos=True, emb_drop=emb_drop)
+        with torch.no_grad():
+            return self.transformer(x0)
 
     # ------------------------------------------------------------------ classification (row a17 / finetune.py)
     def cls_head_fwd(self, y):
@@ -486,6 +532,61 @@ class _SimMIMLossFn(torch.autograd.Function):
         eng.tokenize_bwd(img, mask_u8, dx0)
         grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
         return (None,) * 8 + grads
+
+
+def _refuse_accumulation(eng, names):
+    by_name = dict(eng.trainable())
+    lo, hi = eng.fp.grad.data_ptr(), eng.fp.grad.data_ptr() + 4 * eng.fp.grad.numel()
+    for n in names:
+        p = by_name[n]
+        if p.grad is not None and lo <= p.grad.data_ptr() < hi:
+            raise RuntimeError("call optimizer.zero_grad(set_to_none=True) before the next backward "
+                               "(maskedsst_amd hands autograd views of its flat gradient buffer)")
+
+
+class _TransformerFn(torch.autograd.Function):
+    """y = transformer_forward(tokens): the 2 * depth fused blocks with their HIP backward."""
+
+    @staticmethod
+    def forward(ctx, eng, names, drop, tokens, *params):
+        eng.prep_weights()
+        acts, x1s = eng.blocks_fwd(tokens, save=True, drop=drop)
+        ctx.eng, ctx.names, ctx.drop = eng, names, drop
+        ctx.stash = (acts, x1s)
+        return acts[-1].clone()   # the saved activation must not be modified in place by the caller
+
+    @staticmethod
+    def backward(ctx, dy):
+        eng = ctx.eng
+        acts, x1s = ctx.stash
+        ctx.stash = None
+        _refuse_accumulation(eng, ctx.names)
+        dx0 = eng.blocks_bwd(acts, x1s, dy.contiguous().float().clone(), drop=ctx.drop)
+        grads = tuple(eng.fp.view(n, eng.fp.grad) for n in ctx.names)
+        return (None, None, None, dx0) + grads
+
+
+class _EmbedFn(torch.autograd.Function):
+    """tokens = BlockwisePatchEmbedding.embed(patches) (no position / mask terms) with its HIP backward."""
+
+    @staticmethod
+    def forward(ctx, eng, names, img, *params):
+        ctx.eng, ctx.names = eng, names
+        ctx.stash = (img,)
+        return eng.tokenize(img, None, with_pos=False)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        eng = ctx.eng
+        (img,) = ctx.stash
+        ctx.stash = None
+        _refuse_accumulation(eng, ctx.names)
+        n = img.shape[0] * eng.S * eng.N
+        if eng._zero_mask is None or eng._zero_mask.numel() < n:
+            eng._zero_mask = torch.zeros(n, dtype=torch.uint8, device=img.device)
+        eng.tokenize_bwd(img, eng._zero_mask, dtok.contiguous().float(), with_pos=False)
+        grads = tuple(eng.fp.view(n_, eng.fp.grad) for n_ in ctx.names)
+        return (None, None, None) + grads
 
 
 class _ClassifyFn(torch.autograd.Function):

@@ -21,6 +21,17 @@ import torch
 import torch.distributed as dist
 
 
+def dp_mean(value, group=None):
+    """Mean of a scalar tensor over the data-parallel ranks (identity in a single process).  Used for every number
+    that steers replicated state -- e.g. the validation loss fed to ReduceLROnPlateau (reference pretrain.py:194-197):
+    the all-reduce of the gradients keeps the WEIGHTS equal only while every rank applies the same learning rate."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return value
+    v = value.detach().clone().float().reshape(1)
+    dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+    return (v / dist.get_world_size(group)).reshape(())
+
+
 class BucketReducer:
     def __init__(self, flat_grad, buckets, group=None, bucket_bytes=4 << 20, average_in_optimizer=True):
         """buckets: [(name, start, end)] in the order the backward completes them."""
@@ -118,6 +129,17 @@ class FusedAdamW(torch.optim.Optimizer):
         from . import _lib
         eng = self.model.engine()
         flat, grad, m, v = self._state(eng)
+        # The launch updates the whole trainable prefix of the flat buffer.  torch.optim.AdamW skips parameters
+        # without a gradient; a frozen (requires_grad=False) or unused parameter inside the prefix would instead
+        # receive weight decay plus whatever the gradient buffer last held -- refuse rather than diverge silently.
+        lo, hi = grad.data_ptr(), grad.data_ptr() + 4 * grad.numel()
+        for name, p in eng.trainable():
+            if not p.requires_grad:
+                raise RuntimeError(f"FusedAdamW updates every trainable parameter in one launch; {name!r} has "
+                                   "requires_grad=False -- use torch.optim.AdamW for partially frozen models")
+            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+                raise RuntimeError(f"FusedAdamW.step(): parameter {name!r} has no gradient from the HIP backward of "
+                                   "this step (call loss.backward() first; gradients must be the flat-buffer views)")
         g = self.param_groups[0]
         self._step += 1
         n = eng.fp.n_trainable
@@ -132,6 +154,26 @@ class FusedAdamW(torch.optim.Optimizer):
         d = super().state_dict()
         d["fused"] = dict(step=self._step, m=self._m, v=self._v)
         return d
+
+    def load_state_dict(self, state_dict):
+        """Restores lr / betas / ... through torch and the fused moments + step count saved by ``state_dict``
+        (a resumed run continues the bias correction where it stopped instead of restarting at step 0)."""
+        state_dict = dict(state_dict)
+        fused = state_dict.pop("fused", None)
+        super().load_state_dict(state_dict)
+        if fused is None:
+            raise KeyError("state dict has no 'fused' entry: it was not produced by FusedAdamW.state_dict()")
+        eng = self.model.engine()
+        flat, _, m, v = self._state(eng)
+        self._step = int(fused["step"])
+        if fused["m"] is not None:
+            if fused["m"].numel() != m.numel():
+                raise ValueError(f"fused moments have {fused['m'].numel()} elements, the model needs {m.numel()}")
+            m.copy_(fused["m"].to(m.device))
+            v.copy_(fused["v"].to(v.device))
+        else:
+            m.zero_()
+            v.zero_()
 
 
 def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):

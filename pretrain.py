@@ -25,9 +25,23 @@ import torch
 from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
 from maskedsst_amd.config import get_pretrain_config
 from maskedsst_amd.data import SyntheticCubeLoader
-from maskedsst_amd.optim import FusedAdamW, attach_data_parallel
+from maskedsst_amd.optim import FusedAdamW, attach_data_parallel, dp_mean
 
 SEED = 5
+
+
+def save_checkpoint(save_dir, epoch, model, optimizer, config, losses, img):
+    """the reference's checkpoint dictionary (pretrain.py:135-148): finetune.py / load_checkpoint read
+    ``model_state_dict`` (keys ``mask_token``, ``encoder.*``, ``to_pixels.*``)"""
+    os.makedirs(save_dir, exist_ok=True)
+    cfg = {k: v for k, v in config.__dict__.items() if not isinstance(v, torch.device)}
+    stats = {"losses": torch.stack(losses).cpu(), "config": cfg,
+             "model_state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+             "lr_current": optimizer.param_groups[0]["lr"],
+             "input": img.detach().cpu(), "transformer_input": img.detach().cpu()}
+    path = os.path.join(save_dir, f"model_{config.encoder_name}_ep{epoch}.pth")
+    torch.save(stats, path)
+    return path
 
 
 def main():
@@ -87,6 +101,12 @@ def main():
         tube_masking=config.tube_masking).to(device)
     config.model_params = sum(p.numel() for p in model.parameters())
 
+    if args.torch_optim and world > 1:
+        # torch.optim.AdamW reads p.grad; with the clamp hooks those are fresh tensors, not views of the flat buffer the
+        # bucket reducer all-reduces, and the 1/world mean is applied inside FusedAdamW -- the combination would step every
+        # rank on its local, unaveraged gradients.
+        raise SystemExit("--torch-optim is single-process only: data parallel runs use the fused AdamW "
+                         "(mean + clamp after the all-reduce, inside the optimizer launch)")
     if args.torch_optim:
         optimizer = torch.optim.AdamW(model.parameters(), lr=config.lr, weight_decay=config.weight_decay)
         if config.clip_grad_norm:
@@ -129,17 +149,19 @@ def main():
             if args.max_steps and step >= args.max_steps:
                 break
         loader.close()
-        if args.save_dir and rank == 0 and epoch % config.model_save_freq == 0:
-            os.makedirs(args.save_dir, exist_ok=True)
-            stats = {"losses": torch.stack(losses).cpu(), "config": config.__dict__,
-                     "model_state_dict": model.state_dict(), "lr_current": optimizer.param_groups[0]["lr"],
-                     "input": img.detach(), "transformer_input": img}
-            torch.save(stats, os.path.join(args.save_dir, f"model_{config.encoder_name}_ep{epoch}.pth"))
+        if epoch % config.model_save_freq == 0:     # reference pretrain.py:135-151
+            if args.save_dir and rank == 0:
+                save_checkpoint(args.save_dir, epoch, model, optimizer, config, losses, img)
+            if epoch == 10 and config.model_save_freq == 1:
+                config.model_save_freq = 10
         if not config.skip_val:
             model.eval()
             with torch.no_grad():
                 vt = torch.randn(per_rank, config.n_bands, 8, 8, generator=gen).to(device)
-                scheduler.step(model(vt).item())
+                val_loss = model(vt)
+            # every rank validates on its own shard: the plateau scheduler must see the SAME number everywhere, or the
+            # ranks cut the learning rate at different epochs and the replicas drift apart
+            scheduler.step(dp_mean(val_loss).item())
         if args.max_steps and step >= args.max_steps:
             break
     if world > 1:

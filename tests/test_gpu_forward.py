@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from conftest import load_golden, oracle_cfg_from
-from util import build_product, relerr
+from util import build_product, relerr, record
 
 pytestmark = pytest.mark.gpu
 
@@ -29,10 +29,11 @@ def test_forward_stages(cfg, prec, tol):
         ref = simmim_forward(params, x, ocfg, masks=masks)
     out = model.engine().simmim_forward_stages(x.cuda(), masks[0], masks[1])
     torch.cuda.synchronize()
-    for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred"]:
-        e = relerr(out[k], ref[k])
-        assert e < tol, (k, e)
+    errs = {k: relerr(out[k], ref[k]) for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred"]}
     l, lr = out["loss"].item(), ref["loss"].item()
+    record("forward_stages", cfg=cfg, prec=prec, stage_err=errs, loss_err=abs(l - lr) / abs(lr))
+    for k, e in errs.items():
+        assert e < tol, (k, e)
     assert abs(l - lr) <= tol * abs(lr) + (1e-7 if prec == "fp32" else 1e-4), (l, lr)
     sgn = torch.sign(ref["pred"] - ref["target"])
     if prec == "fp32":

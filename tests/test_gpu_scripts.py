@@ -1,0 +1,148 @@
+"""GPU: the entry points and the rows SURVEY 8f marks "next", end to end on the device.
+
+* f3: ``pretrain.py --save-dir`` writes the reference's checkpoint dictionary; ``finetune.py --checkpoint`` loads it
+  STRICTLY through ``load_checkpoint`` (reference src/utils.py:276-313) and trains on.
+* f4: ``SyntheticCubeLoader``'s pinned staging / asynchronous copies / event-guarded buffer reuse, with the GPU busy.
+* e: the data-parallel wiring (bucket hooks fired by the real HIP backward -> RCCL all-reduce on the process group's
+  stream -> mean inside the fused AdamW) in a FRESH child process started under ``torch.distributed.run`` with one rank.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run(cmd, env=None, timeout=900):
+    e = dict(os.environ)
+    e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    e["PYTHONPATH"] = ROOT + os.pathsep + e.get("PYTHONPATH", "")
+    if env:
+        e.update(env)
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, f"{' '.join(cmd)}\n--- stdout\n{r.stdout[-4000:]}\n--- stderr\n{r.stderr[-4000:]}"
+    return r.stdout
+
+
+def test_pretrain_checkpoint_loads_into_finetune(tmp_path):
+    """two epochs of pretrain.py (depth 4 = the shipped config, validation + plateau scheduler on) -> checkpoint ->
+    finetune.py --checkpoint: strict load (prints '<All keys matched successfully>'), then 10 classification steps."""
+    save = str(tmp_path / "ck")
+    out = run([sys.executable, "pretrain.py", "--batch-size", "8", "--tiles", "16", "--epochs", "2", "--pool-tiles", "8",
+               "--precision", "fp32", "--save-dir", save])
+    files = sorted(os.listdir(save))
+    assert files == ["model_ViTSpatialSpectral_ep0.pth", "model_ViTSpatialSpectral_ep1.pth"], files
+    ck = torch.load(os.path.join(save, files[-1]), map_location="cpu", weights_only=False)
+    assert set(ck) == {"losses", "config", "model_state_dict", "lr_current", "input", "transformer_input"}
+    sd = ck["model_state_dict"]
+    assert "mask_token" in sd and "to_pixels.layers.0.weight" in sd
+    assert sd["encoder.spatial_spectral_transformer.1.layers.3.0.fn.to_qkv.weight"].shape == (1536, 96)
+    assert ck["losses"].numel() == 4 and torch.isfinite(ck["losses"]).all()
+    out = run([sys.executable, "finetune.py", "enmap", "--steps", "10", "--batch-size", "4", "--precision", "fp32",
+               "--checkpoint", os.path.join(save, files[-1])])
+    assert "<All keys matched successfully>" in out, out
+    last = [l for l in out.splitlines() if l.startswith("step 10 ")]
+    assert last and np.isfinite(float(last[0].split()[3])), out
+
+
+def test_loader_async_path_on_gpu():
+    """Every batch that arrives on the device equals the host-side recomputation from the same seed, while a long
+    kernel queue keeps the copy engine and the staging-buffer recycling under pressure (3 staging buffers, 40 batches)."""
+    from maskedsst_amd.data import SyntheticCubeLoader
+    dev = torch.device("cuda")
+    ld = SyntheticCubeLoader(64, 200, image_size=8, pool_tiles=16, steps=40, seed=3, device=dev, prefetch=2)
+    ref = SyntheticCubeLoader(64, 200, image_size=8, pool_tiles=16, steps=0, seed=3, device="cpu")
+    busy = torch.randn(2048, 2048, device=dev)
+    got = []
+    for img in ld:
+        assert img.is_cuda and img.shape == (64, 200, 8, 8)
+        for _ in range(4):                      # keep the stream busy: the copies queue behind real work
+            busy = (busy @ busy).clamp_(-1, 1)
+        got.append(img)
+    torch.cuda.synchronize()
+    assert len(got) == 40
+    for img in got:
+        idx, (x, y) = ref.draw()
+        exp = ref.pool[idx][:, :, x:x + 8, y:y + 8]
+        assert np.array_equal(img.cpu().numpy(), exp)
+    assert all(s.is_pinned() for s in ld.stage)
+    ld.close()
+    ref.close()
+
+
+DP_CHILD = r"""
+import json, os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+from util import build_product
+from maskedsst_amd.optim import FusedAdamW, attach_data_parallel
+
+dp = os.environ.get("MSST_FORCE_DP") == "1"
+torch.cuda.set_device(0)
+if dp:
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+cfg = dict(bands=200, depth=2, B=16)
+model, _, x = build_product(cfg, precision="bf16", device="cuda")
+opt = FusedAdamW(model, lr=0.008, weight_decay=0.05, grad_clamp=1.0)
+red = attach_data_parallel(model, bucket_bytes=256 << 10) if dp else None
+sent = []
+if red is not None:
+    real = dist.all_reduce
+    def counting(t, *a, **k):
+        sent.append((t.data_ptr(), t.numel()))
+        return real(t, *a, **k)
+    dist.all_reduce = counting
+x = x.cuda()
+np.random.seed(11)
+rec = []
+for step in range(3):
+    opt.zero_grad()
+    loss = model(x)
+    loss.backward()
+    if red is not None:
+        opt.grad_scale = red.finish()
+    g = model.engine().fp.grad[: model.engine().fp.n_trainable].clone()
+    opt.step()
+    torch.cuda.synchronize()
+    rec.append(dict(loss=loss.item(), gsum=float(g.double().sum()), gabs=float(g.double().abs().sum()),
+                    g_sha=__import__("hashlib").sha256(g.cpu().numpy().tobytes()).hexdigest()))
+eng = model.engine()
+base = eng.fp.grad.data_ptr()
+out = dict(rec=rec, n_trainable=eng.fp.n_trainable,
+           sent=[((p - base) // 4, n) for p, n in sent],
+           p_sha=__import__("hashlib").sha256(eng.fp.flat.cpu().numpy().tobytes()).hexdigest())
+json.dump(out, open(sys.argv[1], "w"))
+if dp:
+    dist.destroy_process_group()
+"""
+
+
+def test_dp_wiring_single_rank_rccl(tmp_path):
+    """MSST_FORCE_DP=1 under `torch.distributed.run --nproc-per-node 1`: the real backward fires the bucket hooks, RCCL
+    all-reduces every bucket on the process group's stream, FusedAdamW applies the 1/world mean.  With one rank the sum is
+    the identity, so loss, gradients (sha256) and parameters after 3 steps must be BIT-identical to the run without DP,
+    and the all-reduced ranges must tile [0, n_trainable) exactly once per step."""
+    script = tmp_path / "dp_child.py"
+    script.write_text(DP_CHILD)
+    plain, forced = str(tmp_path / "plain.json"), str(tmp_path / "dp.json")
+    run([sys.executable, str(script), plain])
+    run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", "29531", str(script), forced], env={"MSST_FORCE_DP": "1"})
+    a, b = json.load(open(plain)), json.load(open(forced))
+    assert a["rec"] == b["rec"], (a["rec"], b["rec"])
+    assert a["p_sha"] == b["p_sha"]
+    assert not a["sent"] and b["sent"]
+    per_step = len(b["sent"]) // 3
+    assert per_step >= 2 and per_step * 3 == len(b["sent"])
+    for s in range(3):
+        ranges = sorted((o, o + n) for o, n in b["sent"][s * per_step:(s + 1) * per_step])
+        assert ranges[0][0] == 0 and ranges[-1][1] == b["n_trainable"], ranges
+        for (s0, e0), (s1, e1) in zip(ranges, ranges[1:]):
+            assert e0 == s1, ranges

@@ -240,6 +240,52 @@ def test_load_checkpoint_semantics():
         load_checkpoint(Cfg(), enc2, "mlp_head", "cpu", checkpoint=ckpt)
 
 
+def test_load_checkpoint_matches_reference_capture(tmp_path):
+    """The before/after key list and the loaded values captured from the REFERENCE's load_checkpoint
+    (tools/make_golden.py::run_load_checkpoint, src/utils.py:276-313), through a real file written in the reference's
+    checkpoint dictionary by pretrain.py::save_checkpoint: same renames, same drops, the fresh classifier kept, every
+    loaded tensor bit-equal to what the reference loaded (the parameter draw order is the reference's)."""
+    import importlib.util
+    from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
+    from maskedsst_amd.config import Dotdict
+    from maskedsst_amd.utils import load_checkpoint
+    g = load_golden("load_checkpoint_50b_L2.npz")
+    before = bytes(g["before"]).decode().split("\n")
+    after = bytes(g["after"]).decode().split("\n")
+    source = bytes(g["after_source"]).decode().split("\n")
+    cfg = g["cfg"]
+    seed_all(5)
+    enc0 = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10,
+                              num_classes=cfg["n_classes_pretrain"], dim=96, depth=cfg["depth"], heads=8, mlp_dim=64,
+                              dropout=0.0, emb_dropout=0.0, channels=cfg["bands"], spectral_pos_embed=False,
+                              spectral_pos=torch.arange(cfg["bands"] // 10), blockwise_patch_embed=True)
+    mim = SimMIMSpatialSpectral(encoder=enc0, masking_ratio=0.7, mask_patch_size=4, tube_masking=True,
+                                to_pixels_per_spectral_block=True)
+    assert list(mim.state_dict().keys()) == before
+    enc = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10,
+                             num_classes=cfg["n_classes_finetune"], dim=96, depth=cfg["depth"], heads=8, mlp_dim=64,
+                             dropout=0.0, emb_dropout=0.0, channels=cfg["bands"], spectral_pos_embed=False,
+                             spectral_pos=torch.arange(cfg["bands"] // 10), blockwise_patch_embed=True)
+    spec = importlib.util.spec_from_file_location("pretrain_script", os.path.join(ROOT, "pretrain.py"))
+    pre = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pre)
+    opt = torch.optim.SGD(mim.parameters(), lr=0.1)
+    conf = Dotdict(dict(encoder_name="ViTSpatialSpectral", device=torch.device("cpu"), lr=0.1))
+    path = pre.save_checkpoint(str(tmp_path), 0, mim, opt, conf, [torch.zeros(())], torch.zeros(1, cfg["bands"], 8, 8))
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"losses", "config", "model_state_dict", "lr_current", "input", "transformer_input"}  # pretrain.py:137-144
+    assert list(ck["model_state_dict"].keys()) == before
+
+    class Cfg:
+        checkpoint_path, patch_sub, image_size = path, 0, 8
+    load_checkpoint(Cfg(), enc, "mlp_head", "cpu")
+    sd = enc.state_dict()
+    assert list(sd.keys()) == after
+    assert source.count("fresh") == 2 and "other" not in source
+    for k, src in zip(after, source):
+        np.testing.assert_array_equal(fp_np(sd[k]), g["after_fp/" + k], err_msg=f"{k} ({src})")
+
+
 def test_synthetic_cube_loader_contract():
     """pretrain.py:99-107 contract: [B, bands, S, S] windows, one window position per batch, tiles drawn
     from a fixed standardised pool; deterministic under the seed; trailing zero bands for Houston."""

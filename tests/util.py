@@ -1,9 +1,12 @@
 """Shared helpers for the parity tests: build the product model and the oracle parameters from
 the same seed (parameters are drawn on the CPU in the reference order, then moved to the GPU)."""
+import json
+import os
+
 import numpy as np
 import torch
 
-from conftest import seed_all, oracle_cfg_from
+from conftest import ROOT, seed_all, oracle_cfg_from
 
 
 def build_product(cfg, precision="fp32", device="cpu"):
@@ -33,3 +36,20 @@ def relerr(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().reshape(-1)
+    b = b.detach().double().cpu().reshape(-1)
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def record(test, **kv):
+    """Append a measured error to gpurun_out/parity_r02.jsonl (scratch; the round's copy lives in profiles/)."""
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, **kv)) + "\n")
+    except OSError:
+        pass

@@ -271,9 +271,109 @@ def run_finetune_case(name, cfg):
     print(f"finetune {name}: loss={loss.item():.9e} grad_l2={gsq ** 0.5:.6e} n_params={int(out['n_params'])}")
 
 
+def _stub_reference_script_imports():
+    """src/utils.py imports wandb, torchvision, torchmetrics, rasterio and spectral at module level (absent here; none
+    of them is touched by load_checkpoint): satisfy those imports with inert placeholder modules."""
+    import importlib.abc
+    import importlib.machinery
+    import types
+
+    class _Any:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, *a, **k):
+            return _Any()
+
+        def __getattr__(self, k):
+            return _Any()
+
+        def __mro_entries__(self, bases):
+            return (object,)
+
+    class _Stub(types.ModuleType):
+        __path__ = []
+
+        def __getattr__(self, k):
+            if k.startswith("__"):
+                raise AttributeError(k)
+            return _Any()
+
+    class Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+        ROOTS = ("wandb", "torchvision", "torchmetrics", "rasterio", "spectral")
+
+        def find_spec(self, name, path, target=None):
+            if name.split(".")[0] in self.ROOTS:
+                return importlib.machinery.ModuleSpec(name, self, is_package=True)
+
+        def create_module(self, spec):
+            return _Stub(spec.name)
+
+        def exec_module(self, m):
+            pass
+
+    sys.meta_path.insert(0, Finder())
+
+
+def run_load_checkpoint():
+    """Checkpoint hand-off pretrain -> finetune (reference src/utils.py:276-313): a SimMIM state_dict in the
+    reference's checkpoint dictionary (pretrain.py:135-148) is loaded into a fresh encoder with a different class count by
+    the REFERENCE's load_checkpoint.  Stored: the key list before (checkpoint) and after (encoder.state_dict()), which
+    tensors carry checkpoint values / fresh values (fingerprints), so that the product's load_checkpoint can be held to
+    the same renames, drops and strictness without the reference."""
+    import tempfile
+    _stub_reference_script_imports()
+    from src.utils import load_checkpoint
+
+    class Cfg:
+        pass
+
+    cfg = dict(bands=50, depth=2, B=2, n_classes_pretrain=8, n_classes_finetune=20)
+    seed_all()
+    mim = build(dict(bands=50, depth=2, B=2, n_classes=cfg["n_classes_pretrain"]))
+    sd = mim.state_dict()
+    before = list(sd.keys())
+    before_fp = {k: fp(v) for k, v in sd.items()}
+    enc = ViTSpatialSpectral(
+        image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=cfg["n_classes_finetune"],
+        dim=96, depth=2, heads=8, mlp_dim=64, dropout=0.0, emb_dropout=0.0, channels=50,
+        spectral_pos_embed=False, spectral_pos=torch.arange(5), blockwise_patch_embed=True)
+    fresh_fp = {k: fp(v) for k, v in enc.state_dict().items()}
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "ck.pth")
+        torch.save({"model_state_dict": sd, "losses": torch.zeros(1)}, path)
+        c = Cfg()
+        c.checkpoint_path, c.patch_sub, c.image_size = path, 0, 8
+        enc = load_checkpoint(c, enc, "mlp_head", "cpu")
+    after = list(enc.state_dict().keys())
+    out = {
+        "cfg": np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8),
+        "before": np.frombuffer("\n".join(before).encode(), dtype=np.uint8),
+        "after": np.frombuffer("\n".join(after).encode(), dtype=np.uint8),
+    }
+    src = []
+    for k, v in enc.state_dict().items():
+        got = fp(v)
+        if np.array_equal(got, before_fp.get("encoder." + k, None)):
+            src.append("checkpoint")
+        elif np.array_equal(got, fresh_fp[k]):
+            src.append("fresh")
+        else:
+            src.append("other")
+        out["after_fp/" + k] = got
+    out["after_source"] = np.frombuffer("\n".join(src).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(OUT, "load_checkpoint_50b_L2.npz"), **out)
+    print("load_checkpoint:", len(before), "keys before,", len(after), "after;",
+          {s_: src.count(s_) for s_ in set(src)},
+          "dropped:", [k for k in before if not k.startswith("encoder.")][:3], "...")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "load_checkpoint":
+        run_load_checkpoint()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tiny":  # regenerate only the element-wise cases
         run_case("tiny_20b_L1_B2_h2", dict(bands=20, depth=1, B=2, heads=2), full=True)
         run_case("tiny_30b_L1_B3_h2_nontube", dict(bands=30, depth=1, B=3, heads=2, tube_masking=False), full=True)
@@ -295,3 +395,4 @@ if __name__ == "__main__":
     run_adamw_traj()
     run_finetune_case("200b_L4_B2", dict(bands=200, depth=4, B=2, n_classes=8, spectral_pos_embed=False))
     run_finetune_case("50b_L2_B2_specpos", dict(bands=50, depth=2, B=2, n_classes=20, spectral_pos_embed=True))
+    run_load_checkpoint()
