@@ -1,5 +1,7 @@
 # round-end evidence: rocprofv3 kernel stats of the default bench command, the default bench line, PMC passes
-# (HBM traffic; SQ/LDS counters), other configurations.  Everything lands in gpurun_out/final/.
+# (HBM traffic; SQ/LDS counters), other configurations.  Everything lands in gpurun_out/final/;
+# `python tools/make_profiles.py rNN` then copies the judged summaries into profiles/.
+# usage (on the GPU box, through gpurun):  bash tools/final_prof.sh
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

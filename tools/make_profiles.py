@@ -1,4 +1,4 @@
-"""Copy the judged evidence of tools/_final_prof.sh (gpurun_out/final/) into profiles/ (tracked):
+"""Copy the judged evidence of tools/final_prof.sh (gpurun_out/final/) into profiles/ (tracked):
 rocprofv3 kernel stats, bench lines, PMC summaries and the per-launch HBM traffic table bench.py reads."""
 import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -27,7 +27,7 @@ for full, f in fetch.items():
             w = write.get(full, 0.0)
             kern[s] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 "
-                     "--batch 256 (tools/_final_prof.sh), final kernels of the round",
+                     "--batch 256 (tools/final_prof.sh), final kernels of the round",
            "correction": "FETCH_SIZE x2 (gfx950 16B/lane streaming under-report, MI355X_MICROARCH.md), WRITE_SIZE x1; KB -> bytes",
            "kernels": kern}, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
 shutil.copy(os.path.join(SRC, "stats", "r01_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_bench_b256.csv"))

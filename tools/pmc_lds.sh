@@ -1,4 +1,4 @@
-# LDS counters of one kernel for build-flag variants: tools/_pmc_lds.sh file.hip kernel_substr "<flags>" ...
+# LDS counters of one kernel for build-flag variants: tools/pmc_lds.sh file.hip kernel_substr "<flags>" ...
 src=$1; kn=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for flags in "$@"; do
