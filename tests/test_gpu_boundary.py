@@ -89,14 +89,18 @@ def test_transformer_forward_no_grad_matches_autograd_path():
     assert y1.requires_grad and torch.equal(y0, y1.detach())
 
 
-def make_labels(img, n_classes):
-    """learnable synthetic labels: the class of a pixel is the band group with the largest mean (a function of the
-    input the encoder can learn); ~10 % of the pixels are marked ignored (-1) like unlabeled DFC / WorldCover pixels"""
-    B, C, H, W = img.shape
-    g = img.reshape(B, n_classes, C // n_classes, H, W).mean(dim=2)
-    label = g.argmax(dim=1)
-    drop = (img[:, 0] > 1.28)
-    return torch.where(drop, torch.full_like(label, -1), label)
+def make_batch(gen, B, bands, n_classes, amp=1.0):
+    """learnable synthetic task: every pixel gets a random class c and its spectrum a class signature -- +amp on band c
+    of every 10-band spectral patch (a constant offset per patch would be removed by the tokenizer's pre-norm); ~10 % of
+    the pixels are marked ignored (-1) like unlabeled DFC / WorldCover pixels"""
+    img = torch.randn(B, bands, 8, 8, generator=gen)
+    label = torch.randint(0, n_classes, (B, 8, 8), generator=gen)
+    onehot = F.one_hot(label, n_classes).permute(0, 3, 1, 2).float()
+    pat = torch.zeros(B, 10, 8, 8)
+    pat[:, :n_classes] = onehot
+    img = img + amp * pat.repeat(1, bands // 10, 1, 1)
+    drop = torch.rand(B, 8, 8, generator=gen) < 0.1
+    return img, torch.where(drop, torch.full_like(label, -1), label)
 
 
 def test_config5_short_finetune_accuracy_vs_oracle():
@@ -109,9 +113,8 @@ def test_config5_short_finetune_accuracy_vs_oracle():
     ocfg = oracle_cfg_from(cfg)
     steps = 30
     gen = torch.Generator().manual_seed(123)
-    batches = [torch.randn(cfg["B"], cfg["bands"], 8, 8, generator=gen) for _ in range(steps)]
-    held = torch.randn(64, cfg["bands"], 8, 8, generator=gen)
-    held_y = make_labels(held, cfg["n_classes"])
+    batches = [make_batch(gen, cfg["B"], cfg["bands"], cfg["n_classes"]) for _ in range(steps)]
+    held, held_y = make_batch(gen, 64, cfg["bands"], cfg["n_classes"])
 
     def build(prec):
         seed_all(5)
@@ -131,9 +134,9 @@ def test_config5_short_finetune_accuracy_vs_oracle():
     body = [v for k, v in params.items() if "mlp_head" not in k]
     opt = torch.optim.Adam([{"params": body}, {"params": head, "lr": 5e-3}], lr=5e-4, weight_decay=5e-3)
     ref_losses = []
-    for img in batches:
+    for img, y in batches:
         opt.zero_grad()
-        loss = F.cross_entropy(classify_forward(params, img, ocfg), make_labels(img, cfg["n_classes"]), ignore_index=-1)
+        loss = F.cross_entropy(classify_forward(params, img, ocfg), y, ignore_index=-1)
         loss.backward()
         opt.step()
         ref_losses.append(loss.item())
@@ -148,9 +151,9 @@ def test_config5_short_finetune_accuracy_vs_oracle():
         opt = torch.optim.Adam([{"params": body}, {"params": head, "lr": 5e-3}], lr=5e-4, weight_decay=5e-3)
         enc.train()
         losses = []
-        for img in batches:
+        for img, y in batches:
             opt.zero_grad()
-            loss = F.cross_entropy(enc(img.cuda()), make_labels(img, cfg["n_classes"]).cuda(), ignore_index=-1)
+            loss = F.cross_entropy(enc(img.cuda()), y.cuda(), ignore_index=-1)
             loss.backward()
             opt.step()
             losses.append(loss.item())
@@ -160,7 +163,9 @@ def test_config5_short_finetune_accuracy_vs_oracle():
         got[prec] = (acc, losses)
     record("config5_finetune", ref_acc=ref_acc, acc_fp32=got["fp32"][0], acc_bf16=got["bf16"][0],
            ref_loss_last=ref_losses[-1], loss_fp32_last=got["fp32"][1][-1], loss_bf16_last=got["bf16"][1][-1])
-    assert ref_losses[-1] < 0.8 * ref_losses[0], "the synthetic task must be learnable for the comparison to mean anything"
+    # the task is learnable but not saturated after 30 steps (oracle: loss 2.17 -> 0.78, held-out accuracy ~0.73 against
+    # 0.125 chance), so a wrong gradient or update would move the accuracy
+    assert ref_losses[-1] < 0.5 * ref_losses[0] and 0.5 < ref_acc < 0.95, (ref_losses[0], ref_losses[-1], ref_acc)
     np.testing.assert_allclose(got["fp32"][1], ref_losses, rtol=2e-3)
     assert abs(got["fp32"][0] - ref_acc) <= 0.01, (got["fp32"][0], ref_acc)
     assert abs(got["bf16"][0] - ref_acc) <= 0.01, (got["bf16"][0], ref_acc)
