@@ -35,8 +35,13 @@ def grads_pair(cfg, prec):
     return model, params, ref, loss
 
 
-BF16_DX0 = 5e-2
-BF16_GRAD = 5e-2
+# bf16 bars <= 2x measured on MI355X in round 2 (profiles/r02_parity_measured.jsonl), worst of the six cases:
+# dx0 1.65e-3 rel-L2, worst parameter-gradient tensor 6.1e-3 rel-L2 (the tokenizer's pre-norm weight: a 10-element
+# tensor at the end of the whole backward chain), loss 0.7e-4, 1 - cosine 1.2e-4 (B = 2: a handful of flipped L1 signs)
+BF16_DX0 = 3.3e-3
+BF16_GRAD = 1.2e-2
+BF16_LOSS = 1.4e-4
+BF16_COS = 0.99977
 
 
 def rel_l2(a, b):
@@ -69,12 +74,12 @@ def test_param_grads_fp32(cfg):
 def test_param_grads_bf16(cfg):
     """bf16 MFMA mode.  The L1 loss gradient is sign(pred - target): bf16 rounding of the forward
     flips the sign of the few entries with pred ~= target, so element-wise comparison of the
-    end-to-end gradient is not meaningful.  (1) end to end: loss within 1e-3 relative, whole-gradient
-    cosine > 0.99; (2) kernels: with the oracle's sign pattern fed to the backward, every gradient
-    tensor within 5e-2 relative L2 of the oracle."""
+    end-to-end gradient is not meaningful.  (1) end to end: loss and whole-gradient cosine; (2) kernels: with
+    the oracle's sign pattern fed to the backward, dx0 and every gradient tensor in relative L2 against the
+    oracle.  Bars: the BF16_* constants above (<= 2x measured)."""
     model, params, ref, loss = grads_pair(cfg, "bf16")
     lr = ref["loss"].item()
-    assert abs(loss.item() - lr) <= 1e-3 * abs(lr)
+    assert abs(loss.item() - lr) <= BF16_LOSS * abs(lr)
     ga, gb = [], []
     for name, p in model.named_parameters():
         if params[name].grad is not None:
@@ -82,7 +87,7 @@ def test_param_grads_bf16(cfg):
             gb.append(params[name].grad.double().reshape(-1))
     ga, gb = torch.cat(ga), torch.cat(gb)
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
-    assert cos > 0.99, cos
+    assert cos > BF16_COS, cos
     # (2) same sign pattern as the oracle
     from maskedsst_amd.masking import inverse_csr
     eng = model.engine()
@@ -135,13 +140,16 @@ def test_attn_bwd_kernels_agree(cfg, drop, monkeypatch):
     monkeypatch.setenv("MSST_DBG", "16")
     dx_old, g_old = run()
     monkeypatch.delenv("MSST_DBG")
-    assert rel_l2(dx_new, dx_old) < 5e-3
-    bad = []
+    e_dx = rel_l2(dx_new, dx_old)
+    assert e_dx < 5e-4, e_dx   # measured 1.6e-4 (dx), 1.6e-3 (worst gradient tensor)
+    bad, worst = [], 0.0
     for name, p in eng.trainable():
         a, b = eng.fp.view(name, g_new), eng.fp.view(name, g_old)
         if float(b.abs().max()) == 0.0:
             continue
         e = rel_l2(a, b)
-        if not e < 5e-3:
+        worst = max(worst, e)
+        if not e < 3.2e-3:
             bad.append((name, e))
+    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), dx=e_dx, worst_grad=worst)
     assert not bad, bad

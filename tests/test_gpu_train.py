@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from util import build_product
+from util import build_product, record
 
 pytestmark = pytest.mark.gpu
 
@@ -26,9 +26,11 @@ def test_adamw_trajectory_fp32():
         opt.step()
         losses.append(loss.item())
     ref = g["losses"]
-    # steps 1-3 follow the reference closely; lr 0.008 amplifies round-off afterwards
+    dev = [abs(a - b) / abs(b) for a, b in zip(losses, ref)]
+    record("adamw_trajectory_fp32", rel_dev_per_step=dev)
+    # all five steps follow the reference's own trajectory (measured deviations in profiles/r02_parity_measured.jsonl)
     np.testing.assert_allclose(losses[:3], ref[:3], rtol=1e-4)
-    np.testing.assert_allclose(losses[3:], ref[3:], rtol=5e-2)
+    np.testing.assert_allclose(losses[3:], ref[3:], rtol=1e-3)
 
 
 def test_compat_torch_adamw_with_clamp_hooks():
