@@ -9,6 +9,7 @@
 //   tokenize_bwd    grads of the patch embedding, its two LayerNorms, position table and mask token
 //   reduce_slabs    deterministic reduction of the per-workgroup partial-gradient slabs
 #include <atomic>
+#include <type_traits>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 
@@ -1022,7 +1023,10 @@ template <class E>
 __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
     // features per thread: 12 in bf16 mode (8 threads per row, 32 rows per pass: half the registers, twice the waves
     // and bytes in flight of the 24-feature mapping -- this kernel only moves data), 24 in the fp32 parity mode
-    constexpr int FPT = sizeof(E) == 2 ? 12 : 24, TPR = 96 / FPT, ROWS = 256 / TPR, NV = FPT / 4;
+#ifndef MSST_LN1_FPT
+#define MSST_LN1_FPT 12
+#endif
+    constexpr int FPT = sizeof(E) == 2 ? MSST_LN1_FPT : 24, TPR = 96 / FPT, ROWS = 256 / TPR, NV = FPT / 4;
     __shared__ float red[ROWS][97];
     const int tid = threadIdx.x, r = tid / TPR, part = tid % TPR;
     const E* parts = reinterpret_cast<const E*>(a.dxn_part);
@@ -1045,16 +1049,19 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
             f32x4 d1v[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) d1v[i] = d1[i];
+            // widest aligned vector a head's row slice allows: 16 bytes when the slice is a multiple of 16 bytes, else 8
+            constexpr bool W16 = (FPT * (int)sizeof(E)) % 16 == 0;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            constexpr int V8 = FPT * (int)sizeof(E) / 8;    // 8-byte vectors per head row slice
+            typedef typename std::conditional<W16, f32x4, f32x2>::type pvec;
+            constexpr int NPV = FPT * (int)sizeof(E) / (int)sizeof(pvec);
             int h = 0;
             for (; h + 4 <= a.H; h += 4) {
-                f32x2 raw[4][V8];
+                pvec raw[4][NPV];
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {
-                    const f32x2* p = reinterpret_cast<const f32x2*>(parts + ((long)(h + hh) * a.ntok + tok) * 96 + part * FPT);
+                    const pvec* p = reinterpret_cast<const pvec*>(parts + ((long)(h + hh) * a.ntok + tok) * 96 + part * FPT);
 #pragma unroll
-                    for (int q = 0; q < V8; ++q) raw[hh][q] = p[q];
+                    for (int q = 0; q < NPV; ++q) raw[hh][q] = p[q];
                 }
 #pragma unroll
                 for (int hh = 0; hh < 4; ++hh) {

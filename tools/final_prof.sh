@@ -4,8 +4,11 @@
 # usage (on the GPU box, through gpurun):  bash tools/final_prof.sh
 OUT=gpurun_out/final
 rm -rf $OUT; mkdir -p $OUT
+# parity measurements of the round (every bf16 bar in tests/ is <= 2x what this run records)
+rm -f gpurun_out/parity_r02.jsonl
+python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.txt; cat $OUT/gpu_tests.txt
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o r01 -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o r02 -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1
 find $OUT/stats -name "*kernel_trace.csv" -delete
 timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
 tail -1 $OUT/bench_default.json | cut -c1-600
@@ -28,4 +31,9 @@ find $OUT -name "*.csv" -size +512k -delete
   python3 bench.py --no-cpu-baseline --batch 1024 --steps 5 | tail -1
   python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null
 cut -c1-200 $OUT/bench_other_configs.jsonl
+# data-parallel wiring on one GPU: a one-rank RCCL group, bucket hooks fired by the real backward (bench.py --force-dp)
+rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline > $OUT/dp_bench.txt 2>&1
+python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1; cat $OUT/dp_overlap.txt
+find $OUT/dp -name "*.csv" -size +512k -delete
+cp gpurun_out/parity_r02.jsonl $OUT/parity_measured.jsonl 2>/dev/null
 ls -la $OUT $OUT/stats/* | head -30
