@@ -66,12 +66,17 @@ def main():
                     help="event pairs around every kernel in the timed region (default: only the dominant kernel, "
                          "found during warmup; ~150 event pairs per step cost ~5 %% of the step)")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of timed CPU steps per cpu_baseline leg")
+    ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)   # internal: run ONE cpu_baseline leg at this thread count
     ap.add_argument("--no-pipeline", action="store_true",
                     help="skip the second timed region that feeds the loop from SyntheticCubeLoader (input pipeline inclusive rate)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single process, but through the data-parallel path: a one-rank RCCL process group, bucket hooks, "
                          "all-reduce calls, mean inside AdamW (MSST_FORCE_DP=1); for traces of the DP wiring on a 1-GPU box")
     args = ap.parse_args()
+    if args.cpu_leg:
+        cpu_leg(args)
+        return
     if args.force_dp and "RANK" not in os.environ:
         os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MSST_FORCE_DP="1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -259,13 +264,12 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args):
-    """The CPU oracle (oracle/: plain-PyTorch fp32 restatement of the reference, pinned to the reference by
-    tests/golden) doing the same training step -- fwd + autograd bwd + value clamp + torch AdamW, training-mode dropout
-    with the same p as the GPU leg (Bernoulli masks drawn per step like nn.Dropout does) -- on this box's host cores, on
-    a bounded sample.  Two legs, as SURVEY 8d / BASELINE.md section 4 ask: (i) 4 threads, the cap the reference imposes on
-    itself (reference pretrain.py:4-9), (ii) every logical core.  `value` is the faster leg; both are reported."""
+def cpu_leg(args):
+    """One leg of the CPU baseline, run in its own process (`bench.py --cpu-leg THREADS`): the oracle doing the same
+    training step at a fixed thread count; prints one JSON object."""
     from oracle import OracleConfig, init_params, simmim_forward
+    threads = args.cpu_leg
+    torch.set_num_threads(threads)
     cfg = OracleConfig(bands=args.bands, depth=args.depth, heads=args.heads)
     Bc = args.cpu_batch
     p_drop = float(args.dropout)
@@ -280,47 +284,67 @@ def cpu_baseline(args):
             return torch.empty(shape).bernoulli_(keep).div_(keep)
         return {1: m(Bq, cfg.heads, n, n), 2: m(Bq, n, cfg.dim), 3: m(Bq, n, cfg.mlp_dim), 4: m(Bq, n, cfg.dim)}
 
-    def leg(threads, budget_s):
-        torch.set_num_threads(threads)
-        torch.manual_seed(5); np.random.seed(5)
-        params = init_params(cfg)
+    torch.manual_seed(5); np.random.seed(5)
+    params = init_params(cfg)
+    for p in params.values():
+        p.requires_grad_(True)
+    opt = torch.optim.AdamW([p for p in params.values()], lr=0.008, weight_decay=0.05)
+    x = torch.randn(Bc, args.bands, 8, 8)
+
+    def one():
+        opt.zero_grad()
+        out = simmim_forward(params, x, cfg, drop_fn=drop_fn)
+        out["loss"].backward()
         for p in params.values():
-            p.requires_grad_(True)
-        opt = torch.optim.AdamW([p for p in params.values()], lr=0.008, weight_decay=0.05)
-        x = torch.randn(Bc, args.bands, 8, 8)
+            if p.grad is not None:
+                p.grad.clamp_(-1, 1)
+        opt.step()
 
-        def one():
-            opt.zero_grad()
-            out = simmim_forward(params, x, cfg, drop_fn=drop_fn)
-            out["loss"].backward()
-            for p in params.values():
-                if p.grad is not None:
-                    p.grad.clamp_(-1, 1)
-            opt.step()
+    one()  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        if time.perf_counter() - t0 > args.cpu_budget or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    print(json.dumps({"threads": threads, "value": round(n * Bc / dt, 3), "steps": n, "seconds": round(dt, 2)}), flush=True)
 
-        one()  # warm-up
-        n, t0 = 0, time.perf_counter()
-        while True:
-            one()
-            n += 1
-            if time.perf_counter() - t0 > budget_s or n >= 8:
-                break
-        dt = time.perf_counter() - t0
-        return {"threads": threads, "value": round(n * Bc / dt, 3), "steps": n, "seconds": round(dt, 2)}
 
-    prev = torch.get_num_threads()
-    ncpu = os.cpu_count() or prev
-    legs = [leg(4, 12.0)]
-    if ncpu != 4:
-        legs.append(leg(ncpu, 12.0))
-    torch.set_num_threads(prev)
-    best = max(legs, key=lambda l: l["value"])
-    return {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "kind": "port",
-            "legs": legs,
-            "sample": f"bounded sample: up to 8 steps / 12 s per leg of batch {Bc} (same model/config as the GPU leg: "
-                      f"{args.bands} bands, depth {args.depth}x2, fwd+bwd+clamp+AdamW, dropout {p_drop} in training mode), "
-                      f"torch {torch.__version__} CPU fp32; legs at 4 threads (the reference's own cap, pretrain.py:4-9) and at "
-                      f"all {ncpu} logical cores; value = the faster leg"}
+def cpu_baseline(args):
+    """The CPU oracle (oracle/: plain-PyTorch fp32 restatement of the reference, pinned to the reference by
+    tests/golden) doing the same training step -- fwd + autograd bwd + value clamp + torch AdamW, training-mode dropout
+    with the same p as the GPU leg (Bernoulli masks drawn per step like nn.Dropout does) -- on this box's host cores, on
+    a bounded sample.  Two legs, as SURVEY 8d / BASELINE.md section 4 ask: (i) 4 threads, the cap the reference imposes on
+    itself (reference pretrain.py:4-9), (ii) every logical core.  Each leg runs in a child process under a wall-clock
+    limit: with hundreds of threads the many small ops of this model can take minutes per step (measured on a 256-thread
+    box: 354 s for ONE batch-8 step against 2.7 s at 4 threads), and the default bench must finish within minutes; a leg
+    that does not finish in time is reported as such.  `value` is the fastest leg that finished."""
+    import subprocess
+    ncpu = os.cpu_count() or 4
+    legs = []
+    for threads, limit in ((4, 90), (ncpu, 75)) if ncpu != 4 else ((4, 90),):
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--bands", str(args.bands), "--depth",
+               str(args.depth), "--heads", str(args.heads), "--cpu-batch", str(args.cpu_batch), "--dropout", str(args.dropout),
+               "--cpu-budget", str(args.cpu_budget)]
+        env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=limit, env=env)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            legs.append(json.loads(line[-1]) if (r.returncode == 0 and line) else
+                        {"threads": threads, "value": None, "error": (r.stderr or "no output")[-200:]})
+        except subprocess.TimeoutExpired:
+            legs.append({"threads": threads, "value": None,
+                         "timed_out_after_s": round(time.perf_counter() - t0, 1),
+                         "note": "did not finish warm-up + one timed step inside the limit (thread oversubscription on small ops)"})
+    done = [l for l in legs if l.get("value")]
+    best = max(done, key=lambda l: l["value"]) if done else {"value": None, "threads": None}
+    return {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "kind": "port", "legs": legs,
+            "sample": f"bounded sample: up to 8 steps / {args.cpu_budget:.0f} s per leg of batch {args.cpu_batch} (same model/config as the GPU "
+                      f"leg: {args.bands} bands, depth {args.depth}x2, fwd+bwd+clamp+AdamW, dropout {args.dropout} in training mode), torch "
+                      f"{torch.__version__} CPU fp32; legs at 4 threads (the reference's own cap, pretrain.py:4-9) and at all {ncpu} "
+                      f"logical cores, each in a child process under a wall-clock limit; value = the fastest leg that finished"}
 
 
 if __name__ == "__main__":
