@@ -212,11 +212,30 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
             dpre[mt] = tok0 < a.ntok ? *reinterpret_cast<const f32x4*>(a.dy + tok0 * 96 + mt * 16 + 4 * g) : zero4();
         }
     }
+    // Two workgroups per CU (no register room for a whole-tile-ahead prefetch): the rows of a tile are requested
+    // unconditionally from a clamped address, all twelve at once (a load inside `if (valid)` is compiled as request /
+    // s_waitcnt vmcnt(0) / use: six serialised HBM round trips per tile), at the START OF THE WEIGHT-GRAD PHASE of the previous
+    // tile -- the 48 registers of this tile's rows are dead by then and that phase only reads LDS.
+    f32x4 xrow[6], drow[6];
+    auto request_rows = [&](int tile_) {
+        const long t_ = (long)tile_ * 64 + wave * 16 + c;
+        const long tokc = (tile_ < ntiles && t_ < a.ntok) ? t_ : 0;
+        const float* xs = a.x1 + tokc * 96 + 4 * g;
+        const float* ds_ = a.dy + tokc * 96 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) xrow[mt] = *reinterpret_cast<const f32x4*>(xs + mt * 16);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) drow[mt] = *reinterpret_cast<const f32x4*>(ds_ + mt * 16);
+    };
+    if constexpr (!PREF) request_rows(blockIdx.x);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const long tok = (long)tile * 64 + wave * 16 + c;
         const bool valid = tok < a.ntok;
         float xhat[6][4], dyv[6][4];
         float s1 = 0.f;
+        // rows of this tile, requested unconditionally from a clamped address, all twelve before the first is used: a load
+        // inside `if (valid)` is compiled as request / s_waitcnt vmcnt(0) / use -- six serialised HBM round trips per tile
+        // (the rows of this tile are in xrow / drow: requested during the weight-grad phase of the previous tile)
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
             const int m0 = mt * 16 + 4 * g;
@@ -227,9 +246,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
                 const bool vn = tile + (int)gridDim.x < ntiles && tokn < a.ntok;
                 xpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.x1 + tokn * 96 + m0) : zero4();
                 dpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.dy + tokn * 96 + m0) : zero4();
-            } else if (valid) {
-                xr = *reinterpret_cast<const f32x4*>(a.x1 + tok * 96 + m0);
-                dr = *reinterpret_cast<const f32x4*>(a.dy + tok * 96 + m0);
+            } else {
+                xr = valid ? xrow[mt] : zero4();
+                dr = valid ? drow[mt] : zero4();
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) { xhat[mt][r] = xr[r]; dyv[mt][r] = dr[r]; s1 += xr[r]; }
@@ -335,6 +354,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
             }
         }
         lds_barrier();
+        if constexpr (!PREF) request_rows(tile + (int)gridDim.x);
         // ---------------- phase 2: weight grads over the 64 rows of the tile ----------------
 #pragma unroll P::UNROLL
         for (int k0 = 0; k0 < 64; k0 += KS) {
