@@ -312,11 +312,29 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
         f32x4 dxn[6];
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) dxn[mt] = zero4();
-#pragma unroll P::UNROLL
-        for (int k0 = 0; k0 < 64; k0 += KS) {
-            const frag hb = P::ld_kc(&sm.dhp[wave * 16][k0], LDH);
+        if constexpr (TWO) {
+            // two workgroups per CU: the w1^T fragments come from L2.  All twelve are requested before the first MFMA (hp / dh
+            // are dead, 48 registers are free) -- left to the compiler each one was request / s_waitcnt vmcnt(0) / MFMA:
+            // twelve serialised L2 round trips per tile
+            frag w1t[2][6];
 #pragma unroll
-            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(wfrag(2, w1T, 64, mt * 16, k0), hb, dxn[mt]);
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) w1t[ks][mt] = P::ld_w(w1T, 64, mt * 16, ks * KS);
+            const frag hb0 = P::ld_kc(&sm.dhp[wave * 16][0], LDH);
+            const frag hb1 = P::ld_kc(&sm.dhp[wave * 16][KS], LDH);
+            MSST_SCHED_FENCE();
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(w1t[0][mt], hb0, dxn[mt]);
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(w1t[1][mt], hb1, dxn[mt]);
+        } else {
+#pragma unroll P::UNROLL
+            for (int k0 = 0; k0 < 64; k0 += KS) {
+                const frag hb = P::ld_kc(&sm.dhp[wave * 16][k0], LDH);
+#pragma unroll
+                for (int mt = 0; mt < 6; ++mt) dxn[mt] = P::mma(wfrag(2, w1T, 64, mt * 16, k0), hb, dxn[mt]);
+            }
         }
         // LN2 backward + residual
         float g1 = 0.f, g2 = 0.f;
