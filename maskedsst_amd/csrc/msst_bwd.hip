@@ -1177,6 +1177,8 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
 // tokenizer backward (forward: tokenize_fwd_kernel).  grid (S, nchunk), 256 threads.
 // slab per (c, chunk): [dpos N*96 | dW 96*P | db 96 | dpost_g 96 | dpost_b 96 | dmask 96 | dpre_g 16 | dpre_b 16]
 // ==========================================================================================
+// PC: pixels per patch as a compile-time constant (10; 0 = run-time value), see tokenize_fwd_kernel
+template <int PC>
 __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     __shared__ float patch[16][64];
     __shared__ float W[96][17];
@@ -1184,14 +1186,16 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     __shared__ float xn_s[64][17];
     __shared__ float bias[96];
     const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
-    const int P = a.P, N = a.N, T = a.T;
+    const int P = PC ? PC : a.P, N = a.N, T = a.T;
     for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
     if (tid < 96) bias[tid] = a.b_emb[c * 96 + tid];
     const int n = tid >> 2, part = tid & 3;
     const bool active = n < N;
-    float dpos[24], dmask[24], dpg[24], dpb[24], dbc[24];
+    // (the mask-token gradient of this thread's slots is dpos - dpb: every token adds its dt to dpos, the unmasked ones also
+    // to dpb -- one accumulator set less, the kernel sits at the 256-register limit)
+    float dpos[24], dpg[24], dpb[24], dbc[24];
 #pragma unroll
-    for (int i = 0; i < 24; ++i) { dpos[i] = 0.f; dmask[i] = 0.f; dpg[i] = 0.f; dpb[i] = 0.f; dbc[i] = 0.f; }
+    for (int i = 0; i < 24; ++i) { dpos[i] = 0.f; dpg[i] = 0.f; dpb[i] = 0.f; dbc[i] = 0.f; }
     float dpre_g[16], dpre_b[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { dpre_g[k] = 0.f; dpre_b[k] = 0.f; }
@@ -1205,14 +1209,22 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
         const float* src = a.img + ((long)b * a.S + c) * P * N;
         for (int i = tid; i < P * N; i += 256) patch[i / N][i % N] = src[i];
         __syncthreads();
+        // this thread's dx0 slice, requested unconditionally (clamped row) and all six at once: inside `if (active)` every
+        // load was followed by its own s_waitcnt vmcnt(0)
+        f32x4 drow[6];
+        {
+            const int tc = c * N + (active ? n : 0);
+            const f32x4* dsrc = reinterpret_cast<const f32x4*>(a.dx0 + ((long)b * T + tc) * 96 + part * 24);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) drow[i] = dsrc[i];
+        }
         if (active) {
             const int t = c * N + n;
             const bool masked = a.mask[(long)b * T + t] != 0;
             float dt[24];
-            const f32x4* dsrc = reinterpret_cast<const f32x4*>(a.dx0 + ((long)b * T + t) * 96 + part * 24);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                f32x4 t4 = dsrc[i];
+                f32x4 t4 = drow[i];
                 if (a.drop.thr) t4 = drop4(a.drop, 0, (unsigned)(((long)b * T + t) * 24 + part * 6 + i), t4);   // emb dropout backward
                 dt[4*i] = t4[0]; dt[4*i+1] = t4[1]; dt[4*i+2] = t4[2]; dt[4*i+3] = t4[3];
             }
@@ -1221,9 +1233,11 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             // recompute
             float xh0[16], xn[16];
             float mean = 0.f;
+#pragma unroll
             for (int k = 0; k < P; ++k) mean += patch[k][n];
             mean /= P;
             float var = 0.f;
+#pragma unroll
             for (int k = 0; k < P; ++k) { const float d = patch[k][n] - mean; var += d * d; }
             const float rstd = rsqrtf(var / P + 1e-5f);
 #pragma unroll
@@ -1237,6 +1251,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             for (int i = 0; i < 24; ++i) {
                 const int d = part * 24 + i;
                 float acc = bias[d];
+#pragma unroll
                 for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
                 e[i] = acc;
                 s += acc;
@@ -1255,7 +1270,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
                 const int d = part * 24 + i;
                 const float eh = (e[i] - m2) * rstd2;
                 e[i] = eh;
-                if (masked) { dmask[i] += dt[i]; dt[i] = 0.f; }
+                if (masked) dt[i] = 0.f;
                 dpg[i] += dt[i] * eh;
                 dpb[i] += dt[i];
                 dt[i] *= a.post_g[d];
@@ -1274,6 +1289,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
                 const float de = rstd2 * (dt[i] - g1 - e[i] * g2);
                 dbc[i] += de;
                 de_s[n][d] = de;
+#pragma unroll
                 for (int k = 0; k < P; ++k) dxn[k] += W[d][k] * de;
             }
 #pragma unroll
@@ -1313,7 +1329,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
-            const float v = which == 0 ? dbc[i] : which == 1 ? dpg[i] : which == 2 ? dpb[i] : dmask[i];
+            const float v = which == 0 ? dbc[i] : which == 1 ? dpg[i] : which == 2 ? dpb[i] : dpos[i] - dpb[i];
             de_s[n][part * 24 + i] = active ? v : 0.f;
         }
         __syncthreads();
@@ -1433,7 +1449,8 @@ int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
     ProfScope ps(K_TOK_BWD, st);
-    hipLaunchKernelGGL(tokenize_bwd_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    if (a.P == 10) hipLaunchKernelGGL(tokenize_bwd_kernel<10>, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tokenize_bwd_kernel<0>, dim3(a.S, nchunk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 

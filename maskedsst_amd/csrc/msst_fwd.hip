@@ -19,12 +19,15 @@ namespace msst {
 // img [B][C][N] (N = H*W, patch 1x1), spectral block c holds bands c*P .. c*P+P-1: the tile
 // img[b, cP:(c+1)P, :] is P*N contiguous floats -> coalesced load into LDS.
 // ==========================================================================================
+// PC: pixels per patch as a compile-time constant (10 = the reference's spectral patch, configs/config.yaml: band_patch_size)
+// so that the small loops over it unroll and their LDS reads are batched; 0 = run-time value (any P <= 16)
+template <int PC>
 __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     __shared__ float patch[16][64];
     __shared__ float W[96][17];
     __shared__ float bias[96];
     const int c = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
-    const int P = a.P, N = a.N;
+    const int P = PC ? PC : a.P, N = a.N;
     const float* src = a.img + ((long)b * a.S + c) * P * N;
     for (int i = tid; i < P * N; i += 256) patch[i / N][i % N] = src[i];
     for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
@@ -35,11 +38,14 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     // LN over the P raw pixel values (pre_norm, eps 1e-5)
     float xn[16];
     float mean = 0.f;
+#pragma unroll
     for (int k = 0; k < P; ++k) mean += patch[k][n];
     mean /= P;
     float var = 0.f;
+#pragma unroll
     for (int k = 0; k < P; ++k) { const float d = patch[k][n] - mean; var += d * d; }
     const float rstd = rsqrtf(var / P + 1e-5f);
+#pragma unroll
     for (int k = 0; k < P; ++k) xn[k] = (patch[k][n] - mean) * rstd * a.pre_g[k] + a.pre_b[k];
     // per-block Linear(P -> 96): this thread's 24 features
     float e[24];
@@ -48,6 +54,7 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     for (int i = 0; i < 24; ++i) {
         const int d = part * 24 + i;
         float acc = bias[d];
+#pragma unroll
         for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
         e[i] = acc;
         s += acc;
@@ -732,7 +739,8 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* partial, 
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
     ProfScope ps(K_TOK_FWD, st);
-    hipLaunchKernelGGL(tokenize_fwd_kernel, dim3(a.S, a.B), dim3(256), 0, st, a);
+    if (a.P == 10) hipLaunchKernelGGL(tokenize_fwd_kernel<10>, dim3(a.S, a.B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(tokenize_fwd_kernel<0>, dim3(a.S, a.B), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
 
