@@ -306,8 +306,11 @@ class Engine:
     # ------------------------------------------------------------------ autograd entry (SimMIM loss)
     def trainable(self):
         """[(flat name, parameter)] of everything that receives a gradient in pre-training"""
-        groups, _ = self.fp._ordered()
-        return [(n, p) for _, g in groups for n, p in g]
+        if self.fp.flat is None or getattr(self, "_trainable_key", None) != self.fp.version:
+            groups, _ = self.fp._ordered()
+            self._trainable = [(n, p) for _, g in groups for n, p in g]
+            self._trainable_key = self.fp.version if self.fp.flat is not None else None
+        return self._trainable
 
     def dropout_state(self):
         """(p, seed) for this forward: p = transformer dropout when the encoder is in training mode (the

@@ -39,6 +39,7 @@ class FlatParams:
         self.buckets = []               # [(name, start, end)] in backward-completion order
         self.n_trainable = 0            # prefix length that receives gradients in pre-training
         self._ptrs = None
+        self.version = 0                # bumped by every (re)flatten: caches keyed on the layout check it
 
     # ------------------------------------------------------------------
     def _ordered(self):
@@ -113,6 +114,7 @@ class FlatParams:
                     self.buckets.append((bname, start, off))
                     self.n_trainable = off
         self.flat, self.grad = flat, grad
+        self.version += 1
         self._ptrs = tuple(p.data_ptr() for p in allp)
         self.total = total
         return self

@@ -103,6 +103,7 @@ class FusedAdamW(torch.optim.Optimizer):
         self._v = None
         self._step = 0
         self._flat_id = None
+        self._checked_flat = None
 
     def _state(self, eng):
         eng.ensure()
@@ -132,14 +133,18 @@ class FusedAdamW(torch.optim.Optimizer):
         # The launch updates the whole trainable prefix of the flat buffer.  torch.optim.AdamW skips parameters
         # without a gradient; a frozen (requires_grad=False) or unused parameter inside the prefix would instead
         # receive weight decay plus whatever the gradient buffer last held -- refuse rather than diverge silently.
+        # (attribute reads only on the per-step path; the pointer-range check runs on the first step and after a re-flatten)
+        named = eng.trainable()
+        full = self._checked_flat != grad.data_ptr()
         lo, hi = grad.data_ptr(), grad.data_ptr() + 4 * grad.numel()
-        for name, p in eng.trainable():
+        for name, p in named:
             if not p.requires_grad:
                 raise RuntimeError(f"FusedAdamW updates every trainable parameter in one launch; {name!r} has "
                                    "requires_grad=False -- use torch.optim.AdamW for partially frozen models")
-            if p.grad is None or not (lo <= p.grad.data_ptr() < hi):
+            if p.grad is None or (full and not (lo <= p.grad.data_ptr() < hi)):
                 raise RuntimeError(f"FusedAdamW.step(): parameter {name!r} has no gradient from the HIP backward of "
                                    "this step (call loss.backward() first; gradients must be the flat-buffer views)")
+        self._checked_flat = grad.data_ptr()
         g = self.param_groups[0]
         self._step += 1
         n = eng.fp.n_trainable
