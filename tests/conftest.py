@@ -39,7 +39,7 @@ def fp_np(t):
 def oracle_cfg_from(cfg):
     from oracle import OracleConfig
     return OracleConfig(
-        bands=cfg["bands"], depth=cfg["depth"], heads=cfg.get("heads", 8),
+        bands=cfg["bands"], depth=cfg["depth"], heads=cfg.get("heads", 8), image_size=cfg.get("image_size", 8),
         n_classes=cfg.get("n_classes", 8),
         spectral_pos_embed=cfg.get("spectral_pos_embed", False),
         masking_ratio=cfg.get("masking_ratio", 0.7), mask_patch_size=cfg.get("mask_patch_size", 4),

@@ -24,7 +24,7 @@ def run_oracle(g):
     seed_all(5)
     params = init_params(cfg)
     B = g["cfg"]["B"]
-    x = torch.randn(B, cfg.bands, 8, 8)
+    x = torch.randn(B, cfg.bands, cfg.image_size, cfg.image_size)
     if g["cfg"].get("zero_pad_bands"):
         x[:, cfg.bands - g["cfg"]["zero_pad_bands"]:] = 0.0
     for p in params.values():

@@ -13,7 +13,7 @@ def build_product(cfg, precision="fp32", device="cpu"):
     from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral
     seed_all(5)
     enc = ViTSpatialSpectral(
-        image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=cfg.get("n_classes", 8),
+        image_size=cfg.get("image_size", 8), spatial_patch_size=1, spectral_patch_size=10, num_classes=cfg.get("n_classes", 8),
         dim=96, depth=cfg["depth"], heads=cfg.get("heads", 8), mlp_dim=64, dropout=0.0, emb_dropout=0.0,
         channels=cfg["bands"], spectral_pos_embed=cfg.get("spectral_pos_embed", False),
         spectral_pos=torch.arange(cfg["bands"] // 10), blockwise_patch_embed=True, spectral_only=False,
@@ -23,7 +23,7 @@ def build_product(cfg, precision="fp32", device="cpu"):
         mask_patch_size=cfg.get("mask_patch_size", 4),
         to_pixels_per_spectral_block=cfg.get("to_pixels_per_spectral_block", True),
         tube_masking=cfg.get("tube_masking", True))
-    x = torch.randn(cfg["B"], cfg["bands"], 8, 8)
+    x = torch.randn(cfg["B"], cfg["bands"], cfg.get("image_size", 8), cfg.get("image_size", 8))
     if cfg.get("zero_pad_bands"):
         x[:, cfg["bands"] - cfg["zero_pad_bands"]:] = 0.0
     params = {k: v.detach().clone() for k, v in model.state_dict().items()}

@@ -61,7 +61,7 @@ def fp(t):
 
 def build(cfg):
     enc = ViTSpatialSpectral(
-        image_size=8,
+        image_size=cfg.get("image_size", 8),
         spatial_patch_size=1,
         spectral_patch_size=10,
         num_classes=cfg.get("n_classes", 8),
@@ -144,7 +144,7 @@ def run_case(name, cfg, full=False):
     seed_all()
     model = build(cfg)
     B, C = cfg["B"], cfg["bands"]
-    x = torch.randn(B, C, 8, 8)
+    x = torch.randn(B, C, cfg.get("image_size", 8), cfg.get("image_size", 8))
     if cfg.get("zero_pad_bands"):
         x[:, C - cfg["zero_pad_bands"]:] = 0.0
     model.eval()
@@ -374,6 +374,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "load_checkpoint":
         run_load_checkpoint()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "shapes":   # other image sizes / sequence packings (padding rows in the 64-row tiles)
+        run_case("70b_L1_B3_img4_mps2", dict(bands=70, depth=1, B=3, image_size=4, mask_patch_size=2))
+        run_case("30b_L1_B2_img6_mps2_h2", dict(bands=30, depth=1, B=2, image_size=6, mask_patch_size=2, heads=2))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "tiny":  # regenerate only the element-wise cases
         run_case("tiny_20b_L1_B2_h2", dict(bands=20, depth=1, B=2, heads=2), full=True)
         run_case("tiny_30b_L1_B3_h2_nontube", dict(bands=30, depth=1, B=3, heads=2, tube_masking=False), full=True)
@@ -392,6 +396,8 @@ if __name__ == "__main__":
     run_case("50b_L2_B4_specpos", dict(bands=50, depth=2, B=4, spectral_pos_embed=True))
     run_case("50b_L2_B4_sharedpix", dict(bands=50, depth=2, B=4, to_pixels_per_spectral_block=False))
     run_case("50b_L2_B4_mps2_r50", dict(bands=50, depth=2, B=4, mask_patch_size=2, masking_ratio=0.5))
+    run_case("70b_L1_B3_img4_mps2", dict(bands=70, depth=1, B=3, image_size=4, mask_patch_size=2))
+    run_case("30b_L1_B2_img6_mps2_h2", dict(bands=30, depth=1, B=2, image_size=6, mask_patch_size=2, heads=2))
     run_adamw_traj()
     run_finetune_case("200b_L4_B2", dict(bands=200, depth=4, B=2, n_classes=8, spectral_pos_embed=False))
     run_finetune_case("50b_L2_B2_specpos", dict(bands=50, depth=2, B=2, n_classes=20, spectral_pos_embed=True))
