@@ -555,8 +555,8 @@ class _TransformerFn(torch.autograd.Function):
         eng.prep_weights()
         acts, x1s = eng.blocks_fwd(tokens, save=True, drop=drop)
         ctx.eng, ctx.names, ctx.drop = eng, names, drop
-        ctx.stash = (acts, x1s)
-        return acts[-1].clone()   # the saved activation must not be modified in place by the caller
+        ctx.stash = (acts[:-1], x1s)   # block inputs only: the output itself is not needed by the backward
+        return acts[-1]
 
     @staticmethod
     def backward(ctx, dy):
