@@ -133,8 +133,12 @@ def test_dp_wiring_single_rank_rccl(tmp_path):
     script.write_text(DP_CHILD)
     plain, forced = str(tmp_path / "plain.json"), str(tmp_path / "dp.json")
     run([sys.executable, str(script), plain])
+    import socket
+    with socket.socket() as sk:       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-         "--master-port", "29531", str(script), forced], env={"MSST_FORCE_DP": "1"})
+         "--master-port", str(port), str(script), forced], env={"MSST_FORCE_DP": "1"})
     a, b = json.load(open(plain)), json.load(open(forced))
     assert a["rec"] == b["rec"], (a["rec"], b["rec"])
     assert a["p_sha"] == b["p_sha"]
