@@ -21,7 +21,9 @@
 #include "msst_kernels.h"
 
 #ifndef MSST_B2_PERM
-#define MSST_B2_PERM 0   // measured: 12 % fewer bank-conflict cycles, 4 % slower
+#define MSST_B2_PERM 1   // k-permuted transposed fragment reads (rows 4 g + i and 16 + 4 g + i instead of 8 g + i, 8 g + 4 + i: the 32 lanes
+                         // of a ds_read_b64_tr_b16 lane group then touch 8 consecutive rows).  12 % fewer bank-conflict cycles; measured
+                         // +4 % time on the round-1 kernel before the saved-row rework, -1.6 % now (659 -> 648 us, three alternating builds)
 #endif
 #if MSST_B2_PERM
 #define B2_LDKS ld_ks_perm
