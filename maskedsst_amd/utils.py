@@ -27,6 +27,33 @@ def get_optimizers(model, config, fused=True):
     return optimizer, scheduler
 
 
+def get_pos_for_spectral_embedding(spectral_patch_depth, wavelengths, reference_wavelengths):
+    """For every spectral block (``spectral_patch_depth`` consecutive bands, last block ragged) of a sensor with band
+    centres ``wavelengths``: the index of the block of ``reference_wavelengths`` whose mean wavelength is closest
+    (reference src/vit_spatial_spectral.py:767-800).  Used to address the spectral position table of a model pre-trained
+    on the reference sensor with another sensor's bands (Houston2018 on an EnMAP model: [0, 3, 5, 7, 9])."""
+    def block_means(w):
+        w = np.asarray(w, dtype=np.float64)
+        edges = np.arange(0, len(w), spectral_patch_depth)
+        return np.add.reduceat(w, edges) / np.diff(np.append(edges, len(w)))
+    bm, rm = block_means(wavelengths), block_means(reference_wavelengths)
+    return [int(i) for i in np.abs(rm[None, :] - bm[:, None]).argmin(axis=1)]
+
+
+def get_spectral_pos_embedding(dataset, n_bands, band_patch_size, wavelengths=None, reference_wavelengths=None):
+    """reference src/utils.py:415-429: positions of a dataset's spectral tokens in the pre-training sensor's spectral
+    sequence -- the identity for EnMAP-derived data (worldcover / dfc / enmap), the nearest-block lookup for
+    Houston2018 (its band-centre table and the reference sensor's are data the caller supplies; the readers that carry
+    them are out of scope here)."""
+    if dataset in ("worldcover", "dfc", "enmap"):
+        return torch.arange(n_bands // band_patch_size)
+    if dataset == "houston2018":
+        if wavelengths is None or reference_wavelengths is None:
+            raise ValueError("houston2018 needs the band-centre tables of both sensors")
+        return get_pos_for_spectral_embedding(band_patch_size, wavelengths, reference_wavelengths)
+    raise NotImplementedError(f"Unknown dataset {dataset=}")
+
+
 def load_checkpoint(config, model, classifier_name="mlp_head", device="cpu", checkpoint=None):
     """Initialise a bare encoder from a SimMIM pre-training checkpoint, with the reference's semantics
     (src/utils.py:276-313): keys ``encoder.X`` are renamed to ``X``; every other key (``mask_token``,

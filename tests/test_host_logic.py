@@ -286,6 +286,22 @@ def test_load_checkpoint_matches_reference_capture(tmp_path):
         np.testing.assert_array_equal(fp_np(sd[k]), g["after_fp/" + k], err_msg=f"{k} ({src})")
 
 
+def test_houston_spectral_positions_kat():
+    """SURVEY 8c config KAT: Houston2018 spectral tokens address positions [0, 3, 5, 7, 9] of an EnMAP-trained spectral
+    table (reference src/utils.py:415-429); inputs (the two band-centre tables) and outputs captured from the reference,
+    incl. two spectral patch depths with a ragged last block."""
+    from maskedsst_amd.utils import get_pos_for_spectral_embedding, get_spectral_pos_embedding
+    g = load_golden("spectral_pos_houston.npz")
+    assert g["pos_depth10"].tolist() == [0, 3, 5, 7, 9]
+    for depth in (10, 7, 16):
+        got = get_pos_for_spectral_embedding(depth, g["houston_waves"], g["enmap_waves_valid"])
+        assert got == g[f"pos_depth{depth}"].tolist(), depth
+    assert get_spectral_pos_embedding("houston2018", 50, 10, g["houston_waves"], g["enmap_waves_valid"]) == [0, 3, 5, 7, 9]
+    assert get_spectral_pos_embedding("dfc", 200, 10).tolist() == list(range(20))
+    with pytest.raises(NotImplementedError):
+        get_spectral_pos_embedding("sentinel2", 12, 4)
+
+
 def test_synthetic_cube_loader_contract():
     """pretrain.py:99-107 contract: [B, bands, S, S] windows, one window position per batch, tiles drawn
     from a fixed standardised pool; deterministic under the seed; trailing zero bands for Houston."""

@@ -368,9 +368,28 @@ def run_load_checkpoint():
           "dropped:", [k for k in before if not k.startswith("encoder.")][:3], "...")
 
 
+def run_spectral_pos_kat():
+    """Houston2018 -> EnMAP spectral-position lookup (reference src/utils.py:415-429 -> vit_spatial_spectral.py:767-800):
+    the sensors' band-centre tables (data), the reference's answer for the shipped spectral patch depth (the SURVEY 8c KAT
+    [0, 3, 5, 7, 9]) and for two other depths (ragged last block)."""
+    _stub_reference_script_imports()
+    from src.data_enmap import wavelengths as enmap_waves, invalid_l2_bands
+    from src.data_houston2018 import wavelengths as houston_waves
+    from src.vit_spatial_spectral import get_pos_for_spectral_embedding
+    ref = np.array(enmap_waves)[~np.array(invalid_l2_bands)]
+    out = {"houston_waves": np.array(houston_waves, dtype=np.float64), "enmap_waves_valid": ref.astype(np.float64)}
+    for depth in (10, 7, 16):
+        out[f"pos_depth{depth}"] = np.array(get_pos_for_spectral_embedding(depth, houston_waves, ref), dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, "spectral_pos_houston.npz"), **out)
+    print("spectral pos KAT:", out["pos_depth10"].tolist(), len(houston_waves), len(ref))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "spectral_pos":
+        run_spectral_pos_kat()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "load_checkpoint":
         run_load_checkpoint()
         sys.exit(0)
@@ -402,3 +421,4 @@ if __name__ == "__main__":
     run_finetune_case("200b_L4_B2", dict(bands=200, depth=4, B=2, n_classes=8, spectral_pos_embed=False))
     run_finetune_case("50b_L2_B2_specpos", dict(bands=50, depth=2, B=2, n_classes=20, spectral_pos_embed=True))
     run_load_checkpoint()
+    run_spectral_pos_kat()
