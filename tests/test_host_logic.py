@@ -286,6 +286,35 @@ def test_load_checkpoint_matches_reference_capture(tmp_path):
         np.testing.assert_array_equal(fp_np(sd[k]), g["after_fp/" + k], err_msg=f"{k} ({src})")
 
 
+def test_config_bags_match_reference_capture():
+    """SURVEY 8c config KAT: the merged hyper-parameter bags of the reference's loaders on the reference's YAML files
+    (captured by tools/make_golden.py::run_config_kat) against this repo's loaders on this repo's YAML files: same keys,
+    same values, except the documented deviations (dataset paths are placeholders; the finetune config keeps the position
+    embedding mode of the shipped PRETRAIN config so that its checkpoints load -- SURVEY 3.3 quirk)."""
+    import importlib.util
+    import json
+    from maskedsst_amd.config import get_pretrain_config
+    ref = json.loads(bytes(np.load(os.path.join(ROOT, "tests", "golden", "config_kat.npz"))["json"]).decode())
+    pre = get_pretrain_config(os.path.join(ROOT, "configs", "pretrain_config.yaml"),
+                              os.path.join(ROOT, "configs", "config.yaml"), 5, "cpu").__dict__
+    spec = importlib.util.spec_from_file_location("finetune_script", os.path.join(ROOT, "finetune.py"))
+    fin_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fin_mod)
+    fin = fin_mod.get_finetune_config(os.path.join(ROOT, "configs", "finetune_config_enmap.yaml"),
+                                      os.path.join(ROOT, "configs", "config.yaml"), 5, "cpu").__dict__
+    deviations = {"pretrain": {"train_path": None}, "finetune_enmap": {"train_path": None, "checkpoint_path": None,
+                                                                       "spectral_pos_embed": False}}
+    for name, got in (("pretrain", pre), ("finetune_enmap", fin)):
+        want = ref[name]
+        assert set(got) == set(want), (name, set(got) ^ set(want))
+        for k, v in want.items():
+            g = got[k].tolist() if torch.is_tensor(got[k]) else got[k]
+            if k in deviations[name]:
+                assert g == deviations[name][k], (name, k, g)
+            else:
+                assert g == v, (name, k, g, v)
+
+
 def test_houston_spectral_positions_kat():
     """SURVEY 8c config KAT: Houston2018 spectral tokens address positions [0, 3, 5, 7, 9] of an EnMAP-trained spectral
     table (reference src/utils.py:415-429); inputs (the two band-centre tables) and outputs captured from the reference,

@@ -368,6 +368,33 @@ def run_load_checkpoint():
           "dropped:", [k for k in before if not k.startswith("encoder.")][:3], "...")
 
 
+def run_config_kat():
+    """Merged hyper-parameter bags of the reference's own config loaders on the reference's own YAML files
+    (src/utils.py:316-364): every key and every value that is not a filesystem path."""
+    _stub_reference_script_imports()
+    from src.utils import get_pretrain_config, get_finetune_config
+    cwd = os.getcwd()
+    os.chdir(REF)
+    try:
+        pre = get_pretrain_config("configs/pretrain_config.yaml", "configs/config.yaml", SEED, "cpu").__dict__
+        fin = get_finetune_config("configs/finetune_config_enmap.yaml", "configs/config.yaml", SEED, "cpu").__dict__
+    finally:
+        os.chdir(cwd)
+
+    def clean(d):
+        out = {}
+        for k, v in d.items():
+            if torch.is_tensor(v):
+                v = v.tolist()
+            if isinstance(v, str) and ("/" in v):
+                v = "<path>"
+            out[k] = v
+        return out
+    blob = json.dumps({"pretrain": clean(pre), "finetune_enmap": clean(fin)}, sort_keys=True)
+    np.savez_compressed(os.path.join(OUT, "config_kat.npz"), json=np.frombuffer(blob.encode(), dtype=np.uint8))
+    print("config KAT:", len(pre), "pretrain keys,", len(fin), "finetune keys")
+
+
 def run_spectral_pos_kat():
     """Houston2018 -> EnMAP spectral-position lookup (reference src/utils.py:415-429 -> vit_spatial_spectral.py:767-800):
     the sensors' band-centre tables (data), the reference's answer for the shipped spectral patch depth (the SURVEY 8c KAT
@@ -389,6 +416,9 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "spectral_pos":
         run_spectral_pos_kat()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "config":
+        run_config_kat()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "load_checkpoint":
         run_load_checkpoint()
@@ -422,3 +452,4 @@ if __name__ == "__main__":
     run_finetune_case("50b_L2_B2_specpos", dict(bands=50, depth=2, B=2, n_classes=20, spectral_pos_embed=True))
     run_load_checkpoint()
     run_spectral_pos_kat()
+    run_config_kat()
