@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--synthetic", action="store_true", default=True)
     ap.add_argument("--tiles", type=int, default=256, help="synthetic 64x64 tiles per epoch")
     ap.add_argument("--pool-tiles", type=int, default=64, help="distinct synthetic tiles held in host memory")
+    ap.add_argument("--val-tiles", type=int, default=4, help="synthetic 64x64 validation tiles per rank (sliding-window validation)")
     ap.add_argument("--epochs", type=int, default=None)
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--depth", type=int, default=None)
@@ -115,11 +116,17 @@ def main():
     else:
         optimizer = FusedAdamW(model, lr=config.lr, weight_decay=config.weight_decay,
                                grad_clamp=1.0 if config.clip_grad_norm else 0.0)
-    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=5)
+    if config.scheduler == "cosine":       # reference src/utils.py:47-59
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=50, eta_min=0, last_epoch=-1)
+    else:
+        scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=5)
     reducer = attach_data_parallel(model) if world > 1 else None
 
     # synthetic standardised tiles [bands, 64, 64] (per-band N(0,1), like StandardizeEnMAP output), cropped per batch
     gen = torch.Generator().manual_seed(SEED + 1000 * rank)
+    val_tiles = None
+    if not config.skip_val:   # this rank's held-out tiles (resident: args.val_tiles x bands x 64 x 64 floats)
+        val_tiles = torch.randn(args.val_tiles, config.n_bands, 64, 64, generator=gen).to(device)
     per_rank = config.batch_size // world
     steps_per_epoch = max(1, args.tiles // config.batch_size)
 
@@ -155,13 +162,22 @@ def main():
             if epoch == 10 and config.model_save_freq == 1:
                 config.model_save_freq = 10
         if not config.skip_val:
+            # validation as in the reference (pretrain.py:155-197): eval mode, no_grad, every image_size x image_size window
+            # of the held-out 64 x 64 tiles (stride = window size), mean loss -> ReduceLROnPlateau
             model.eval()
+            val_losses = []
             with torch.no_grad():
-                vt = torch.randn(per_rank, config.n_bands, 8, 8, generator=gen).to(device)
-                val_loss = model(vt)
+                s_ = config.image_size
+                for x0 in range(0, 64, s_):
+                    for y0 in range(0, 64, s_):
+                        val_losses.append(model(val_tiles[:, :, x0:x0 + s_, y0:y0 + s_].contiguous()))
+            val_loss = torch.stack(val_losses).mean()
             # every rank validates on its own shard: the plateau scheduler must see the SAME number everywhere, or the
             # ranks cut the learning rate at different epochs and the replicas drift apart
-            scheduler.step(dp_mean(val_loss).item())
+            if config.scheduler == "ReduceLROnPlateau":
+                scheduler.step(dp_mean(val_loss).item())
+        if config.scheduler == "cosine":
+            scheduler.step()
         if args.max_steps and step >= args.max_steps:
             break
     if world > 1:
