@@ -38,6 +38,7 @@ extern "C" {
  * the library never reads the environment and keeps no per-call state. */
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
+#define MSST_KERNEL_ATTN_R2 (32 << 8)    /* bf16 attention backward: the round-2 kernel (16x16x32 tiles)     */
 
 #define MSST_MODE_SPATIAL 0  /* sequences = (b, c), N tokens each, contiguous            */
 #define MSST_MODE_SPECTRAL 1 /* sequences = (b, n), S tokens each, stride N*96 floats    */
@@ -52,7 +53,8 @@ const char* msst_last_error(void);
 typedef struct MsstPrepJob {
     const float* src; /* [rows][cols] fp32 master weight          */
     void* dst;        /* [rows][cols] or [cols][rows] (transpose) */
-    int32_t rows, cols, transpose, _pad;
+    int32_t rows, cols, transpose;
+    int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA) */
 } MsstPrepJob;
 
 /* Converts / transposes all matrices of the model into operand layout in ONE launch.
@@ -72,6 +74,11 @@ typedef struct MsstBlockWeights {
     const void* w2T;   /* [64][96]                                             */
     const float* ln1_g; const float* ln1_b; const float* bo;
     const float* ln2_g; const float* ln2_b; const float* b1; const float* b2;
+    /* bf16 only, optional (null: msst_block_bwd runs the round-2 attention backward): the three matrices the round-3
+     * attention backward feeds to 32x32x16 MFMAs, fragment-packed with MsstPrepJob.pack = 1 */
+    const void* wqkv32;  /* [3*H*64][96]  */
+    const void* woutT32; /* [H*64][96]    */
+    const void* wqkvT32; /* [96][3*H*64]  */
 } MsstBlockWeights;
 
 /* a1+a2+a3+a5: BlockwisePatchEmbedding.to_patch/.embed (vit_spatial_spectral.py:197-222), position

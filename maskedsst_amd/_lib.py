@@ -25,13 +25,13 @@ class MsstError(RuntimeError):
 
 class MsstPrepJob(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int32), ("cols", c_int32),
-                ("transpose", c_int32), ("_pad", c_int32)]
+                ("transpose", c_int32), ("pack", c_int32)]
 
 
 class MsstBlockWeights(Structure):
     _fields_ = [(n, c_void_p) for n in (
         "wqkv", "wout", "w1", "w2", "wqkvT", "woutT", "w1T", "w2T",
-        "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2")]
+        "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2", "wqkv32", "woutT32", "wqkvT32")]
 
 
 class MsstBlockGrads(Structure):

@@ -40,9 +40,15 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
             // fragment-packed destination (see PBF16::ld_w): logical (r, c) of the [R][K] destination matrix
             const int K = j.transpose ? j.rows : j.cols;
             const int r = i / K, c = i - r * K;
-            const int f = (r >> 4) * (K >> 5) + (c >> 5);
-            const int lane = ((c & 31) >> 3) * 16 + (r & 15);
-            dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+            if (j.pack == 1) {   // 32 rows x 16 k per fragment (v_mfma_f32_32x32x16_bf16 operand: lane = row % 32 + 32 (k % 16 / 8))
+                const int f = (r >> 5) * (K >> 4) + (c >> 4);
+                const int lane = ((c & 15) >> 3) * 32 + (r & 31);
+                dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+            } else {
+                const int f = (r >> 4) * (K >> 5) + (c >> 5);
+                const int lane = ((c & 31) >> 3) * 16 + (r & 15);
+                dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+            }
         }
     }
 }
@@ -126,6 +132,7 @@ static BlockWeights to_bw(const MsstBlockWeights* w) {
     b.wqkvT = w->wqkvT; b.woutT = w->woutT; b.w1T = w->w1T; b.w2T = w->w2T;
     b.ln1_g = w->ln1_g; b.ln1_b = w->ln1_b; b.bo = w->bo;
     b.ln2_g = w->ln2_g; b.ln2_b = w->ln2_b; b.b1 = w->b1; b.b2 = w->b2;
+    b.wqkv32 = w->wqkv32; b.woutT32 = w->woutT32; b.wqkvT32 = w->wqkvT32;
     return b;
 }
 

@@ -1428,7 +1428,9 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
         ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
     } else if (!(a.dbg & 16)) {
-        return launch_block_bwd_attn_bf16(a, nchunk, st);   // MSST_DBG=16 selects the template kernel below (reference for the tuned one)
+        // MSST_DBG=16 selects the template kernel below (reference for the tuned ones), 32 the round-2 tuned kernel
+        if (!(a.dbg & 32) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) return launch_block_bwd_attn_r3(a, nchunk, st);
+        return launch_block_bwd_attn_bf16(a, nchunk, st);
     } else {
         const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad
         int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);

@@ -24,6 +24,7 @@ struct BlockWeights {
     const void* w2T;    // [64][96]
     const float* ln1_g; const float* ln1_b; const float* bo;
     const float* ln2_g; const float* ln2_b; const float* b1; const float* b2;
+    const void* wqkv32; const void* woutT32; const void* wqkvT32;   // bf16, 32 x 16 fragment packing (optional)
 };
 
 struct BlockArgs {
@@ -168,7 +169,8 @@ struct RSegBuilder {
 int launch_reduce_segs(const RSegs& r, hipStream_t st);
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st);
-int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st);   // msst_bwd2.hip (bf16 throughput kernel)
+int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st);   // msst_bwd2.hip (round-2 bf16 kernel, 16x16x32 tiles)
+int launch_block_bwd_attn_r3(const AttnBwdArgs& a, int nchunk, hipStream_t st);     // msst_bwd3.hip (bf16 throughput kernel: one GEMM per wave, 32x32x16 tiles)
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st);
 int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st);
