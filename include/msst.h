@@ -54,7 +54,8 @@ typedef struct MsstPrepJob {
     const float* src; /* [rows][cols] fp32 master weight          */
     void* dst;        /* [rows][cols] or [cols][rows] (transpose) */
     int32_t rows, cols, transpose;
-    int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA) */
+    int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA),
+                         2 = as 1, and the first two thirds of the SOURCE rows (the q and k blocks of to_qkv) scaled by 2^-3 */
 } MsstPrepJob;
 
 /* Converts / transposes all matrices of the model into operand layout in ONE launch.
@@ -78,7 +79,7 @@ typedef struct MsstBlockWeights {
      * attention backward feeds to 32x32x16 MFMAs, fragment-packed with MsstPrepJob.pack = 1 */
     const void* wqkv32;  /* [3*H*64][96]  */
     const void* woutT32; /* [H*64][96]    */
-    const void* wqkvT32; /* [96][3*H*64]  */
+    const void* wqkvT32; /* [96][3*H*64], pack = 2 (q and k blocks carry the softmax scale) */
 } MsstBlockWeights;
 
 /* a1+a2+a3+a5: BlockwisePatchEmbedding.to_patch/.embed (vit_spatial_spectral.py:197-222), position

@@ -33,14 +33,17 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
             const int c = i / j.rows, r = i - c * j.rows;  // dst[c][r] = src[r][c]
             src_i = r * j.cols + c;
         }
-        const float v = j.src[src_i];
+        float v = j.src[src_i];
+        // pack 2 (to_qkv^T for the round-3 attention backward): the q and k blocks carry the softmax scale dim_head^-0.5 = 2^-3,
+        // exact in bf16 -- that kernel keeps dq / dk unscaled (reference vit_spatial_spectral.py:54,71)
+        if (j.pack == 2 && src_i / j.cols < 2 * (j.rows / 3)) v *= 0.125f;
         if constexpr (sizeof(E) == 4) {
             dst[i] = v;
         } else {
             // fragment-packed destination (see PBF16::ld_w): logical (r, c) of the [R][K] destination matrix
             const int K = j.transpose ? j.rows : j.cols;
             const int r = i / K, c = i - r * K;
-            if (j.pack == 1) {   // 32 rows x 16 k per fragment (v_mfma_f32_32x32x16_bf16 operand: lane = row % 32 + 32 (k % 16 / 8))
+            if (j.pack >= 1) {   // 32 rows x 16 k per fragment (v_mfma_f32_32x32x16_bf16 operand: lane = row % 32 + 32 (k % 16 / 8))
                 const int f = (r >> 5) * (K >> 4) + (c >> 4);
                 const int lane = ((c & 15) >> 3) * 32 + (r & 31);
                 dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);

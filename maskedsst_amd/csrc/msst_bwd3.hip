@@ -33,6 +33,12 @@
 #ifndef MSST_B3_D4
 #define MSST_B3_D4 3    // phase 4
 #endif
+#ifndef MSST_B3_W4
+#define MSST_B3_W4 6    // phase-4 weight fragments requested before the weight-gradient GEMM (the other 12 - n during phase 4)
+#endif
+#ifndef MSST_B3_W1AT
+#define MSST_B3_W1AT 6   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
+#endif
 #ifndef MSST_B3_EXP
 #define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = no row requests
 #endif
@@ -59,7 +65,7 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 // LDS map (bytes).  64-wide bf16 tiles: 128-byte rows; 96-wide tiles: 192-byte rows.
 constexpr int R3_XN = 0, R3_DA = 12288;
 constexpr int R3_Q = 24576, R3_K = 32768, R3_DO = 40960, R3_V = 49152, R3_P = 57344, R3_DS = 65536, R3_SMEM = 73728;
-constexpr int R3_OUT = R3_V;   // [64][96] staging of the d(LN1 out) rows (v and P are dead by then: 16 KB)
+constexpr int R3_OUT = R3_P;   // [64][96] staging of the d(LN1 out) rows in P | dS (dead after phase 3; next written in phase 2, behind barrier B1)
 
 // 16-byte slot s of row r lives at slot s ^ fz(r) (128-byte rows) / (s & ~3) | ((s & 3) ^ fz2(r)) (192-byte rows)
 __device__ __forceinline__ int fz(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 3) & 1); }
@@ -166,9 +172,8 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
         return (unsigned)(row * 192 + (((s & ~3) | ((s & 3) ^ fz2(row))) << 4));
     };
     // The LN1(x) / da rows of the NEXT tile are staged through registers: thread <-> (row tid / 4, 48 bytes), three 16-byte loads
-    // of each array.  They are requested at the start of the weight-gradient GEMM (an HBM round trip under load is 2-3 k cycles:
-    // anything later leaves the barrier at the top of the next tile waiting for them) and stored into XN / DA -- dead from
-    // barrier B3 on, phase 4 stages its result in V | P -- at the end of phase 4.  Padding rows: clamped address, zeros stored.
+    // of each array.  They are requested at the start of the weight-gradient GEMM (an HBM round trip under load is 2-3 k cycles)
+    // and stored into XN / DA -- dead from barrier B3 on -- before barrier B4.  Padding rows: clamped address, zeros stored.
     auto load_rows = [&](int tile_, u32x4 (&xr)[3], u32x4 (&dr)[3]) -> int {
         const int t_ = launder3(tid);
         const int tok = (MSST_B3_EXP & 4) ? 0 : tok_sp(tile_, rowmap[t_ >> 2]);
@@ -193,13 +198,16 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
         store_rows(tok0, xr, dr);
     }
     s16x8 w1[2][4];   // phase-1 weight fragments [d tile][k step % 4]: a ring of four k-steps (tile invariant, re-requested from L2 every tile)
-    {
+#define W1_(dt, s4) w1[(dt)][(s4)]
+    auto load_w1 = [&]() {
         const int l16 = (launder3(tid) & 63) * 16;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
-    }
+            for (int ks = 0; ks < 4; ++ks) W1_(dt, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
+    };
+    load_w1();
+    lds_barrier();   // the first tile's rows are in XN / DA
 
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
 #if defined(MSST_STAMPS)
@@ -215,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #define R3_DUMP(stage) do { } while (0)
 #endif
         STAMP(0);
-        lds_barrier();   // B0: LN1(x) and da rows of this tile are in XN / DA
         STAMP(1);
         B3_PRIO(1);
         R3_DUMP(0);
@@ -239,13 +246,13 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     fb[ks % 3][1] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + 32 * 192);
                 },
                 [&](int ks) {
-                    c[0][0] = mma32(w1[0][ks & 3], fb[ks % 3][0], c[0][0]);
-                    c[0][1] = mma32(w1[0][ks & 3], fb[ks % 3][1], c[0][1]);
-                    c[1][0] = mma32(w1[1][ks & 3], fb[ks % 3][0], c[1][0]);
-                    c[1][1] = mma32(w1[1][ks & 3], fb[ks % 3][1], c[1][1]);
+                    c[0][0] = mma32(W1_(0, ks & 3), fb[ks % 3][0], c[0][0]);
+                    c[0][1] = mma32(W1_(0, ks & 3), fb[ks % 3][1], c[0][1]);
+                    c[1][0] = mma32(W1_(1, ks & 3), fb[ks % 3][0], c[1][0]);
+                    c[1][1] = mma32(W1_(1, ks & 3), fb[ks % 3][1], c[1][1]);
                     if (ks < 2) {
-                        w1[0][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + ks + 4, (t_ & 63) * 16);
-                        w1[1][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 + ks + 4, (t_ & 63) * 16);
+                        W1_(0, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + ks + 4, (t_ & 63) * 16);
+                        W1_(1, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 + ks + 4, (t_ & 63) * 16);
                     }
                 });
             const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
@@ -300,7 +307,15 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #pragma unroll
                 for (int t = 0; t < 4; ++t) fv[ks2][t] = lds_r128(sm, R3_V + ak[ks2] + t * 2048);
             }
-            unsigned keep1 = 0;
+            // dP^T = v dO^T is independent of the softmax: its MFMAs run under the softmax's VALU work
+            f32x4 dp[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dp[t] = zero4();
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) dp[t] = P::mma(fv[ks2][t], fdo[ks2], dp[t]);   // C[i = key][j = query]
+            f32x4 dm[4];   // dropout multipliers of site 1 (0 or 1 / (1 - p)): P and dP see the same ones
             {
                 // same arithmetic as block_fwd_hw_kernel: exp2(s c - max c), c = scale log2 e; nothing to mask when L == 64
                 const float cs = a.scale * 1.44269504088896340736f;
@@ -335,24 +350,22 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     pr[t] = pr[t] * inv;
                     f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                     if (DROP) {
-                        unsigned kb;
-                        pd = drop4_keep(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), pd, kb);
-                        keep1 |= kb << (4 * t);
+                        unsigned ha, hb;
+                        drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
+                        const unsigned t16 = a.drop.thr << 16;
+                        dm[t][0] = (ha << 16) >= t16 ? a.drop.scale : 0.f;
+                        dm[t][1] = ha >= t16 ? a.drop.scale : 0.f;
+                        dm[t][2] = (hb << 16) >= t16 ? a.drop.scale : 0.f;
+                        dm[t][3] = hb >= t16 ? a.drop.scale : 0.f;
+                        pd = pd * dm[t];
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
                 }
             }
             {
-                f32x4 dp[4];
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dp[t] = zero4();
-#pragma unroll
-                for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dp[t] = P::mma(fv[ks2][t], fdo[ks2], dp[t]);   // C[i = key][j = query]
                 if (DROP) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) dp[t] = drop4_bits(a.drop, keep1 >> (4 * t), dp[t]);
+                    for (int t = 0; t < 4; ++t) dp[t] = dp[t] * dm[t];
                 }
                 float delta = 0.f;
 #pragma unroll
@@ -360,28 +373,28 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #pragma unroll
                     for (int r = 0; r < 4; ++r) delta += pr[t][r] * dp[t][r];
                 delta = colgroup_sum(delta);
+                // dS WITHOUT the softmax scale (dim_head^-0.5 = 2^-3, exact in bf16): it is folded into the q / k blocks of the
+                // phase-4 weights (msst_prep_weights, pack = 2) and into the dWq / dWk slabs at the end of the kernel
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f32x4 d4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta) * a.scale;
-                    lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key]
+                    for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta);
+                    lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
             }
         }
         STAMP(4);
-        lds_barrier();   // B2
-        STAMP(5);
-        B3_PRIO(1);
-        R3_DUMP(2);
         // ---------------- phase 3: the four contractions over rows, one per wave ----------------
         //   Q: dq[query][d] = sum_key dS[query][key] k[key][d]      O: o[query][d] = sum_key P[query][key] v[key][d]     (path X)
         //   K: dk[key][d]   = sum_query dS[query][key] q[query][d]  V: dv[key][d]  = sum_query P[query][key] dO[query][d] (path Y)
         // C[i = row][j = d]; then G[d][m] += sum_row C[row][d] . {LN1(x) | da}[row][m] with the packed C tiles as A operand.
-        s16x8 w4[6];            // phase-4 weight fragments of this wave's m tile: a ring of six, refilled as phase 4 consumes them
-        u32x4 xnq[3], daq[3];   // rows of the next tile
-        int tokn;
+        // The second operand (k | q | dO | v) has been complete since barrier B1: its first fragments are requested BEFORE
+        // barrier B2, so the phase starts with its MFMAs instead of an LDS round trip.
         {
+            s16x8 w4[6];            // phase-4 weight fragments of this wave's m tile: a ring of six, refilled as phase 4 consumes them
+            u32x4 xnq[3], daq[3];   // rows of the next tile
+            int tokn;
             const int t_ = launder3(tid);
             const int l = t_ & 63, l31 = l & 31, hi = l >> 5, i = l & 15, u = (l >> 4) & 1, b = (i >> 1) & 1, r1 = (i >> 3) & 1;
             // transposed 32-column fragment of a 64-wide tile, natural contraction order: k row = 16 kk + 8 hi + 4 a + i / 4
@@ -391,44 +404,70 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
                 for (int aa = 0; aa < 2; ++aa) tr[ct][aa] = (Lt ^ ((ct << 6) | (aa << 5))) + 512 * aa;
+            const unsigned a1 = p3_a1 + l31 * 128 + ((hi ^ fz(l31)) << 4);   // path X first operand: ^ (kk << 5), + 4096 row tile
             f32x16 c[2][2];   // [row tile][d tile]
 #pragma unroll
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) c[ii][j] = zero16();
-            s16x8 fa[MSST_B3_D3A + 1][2], fb[MSST_B3_D3A + 1][2];   // [slot][tile], MSST_B3_D3A k-steps ahead
-            if (pathX) {
-                const unsigned a1 = p3_a1 + l31 * 128 + ((hi ^ fz(l31)) << 4);   // ^ (kk << 5), + 4096 row tile
-                swpipe<4, MSST_B3_D3A>(
-                    [&](int kk) {
-                        fa[kk % (MSST_B3_D3A + 1)][0] = lds_r128(sm, a1 ^ (kk << 5));
-                        fa[kk % (MSST_B3_D3A + 1)][1] = lds_r128(sm, (a1 ^ (kk << 5)) + 4096);
-                        fb[kk % (MSST_B3_D3A + 1)][0] = lds_tr2(sm, p3_a2 + tr[0][0] + 2048 * kk, p3_a2 + tr[0][1] + 2048 * kk);
-                        fb[kk % (MSST_B3_D3A + 1)][1] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * kk, p3_a2 + tr[1][1] + 2048 * kk);
-                    },
-                    [&](int kk) {
-                        c[0][0] = mma32(fa[kk % (MSST_B3_D3A + 1)][0], fb[kk % (MSST_B3_D3A + 1)][0], c[0][0]);
-                        c[0][1] = mma32(fa[kk % (MSST_B3_D3A + 1)][0], fb[kk % (MSST_B3_D3A + 1)][1], c[0][1]);
-                        c[1][0] = mma32(fa[kk % (MSST_B3_D3A + 1)][1], fb[kk % (MSST_B3_D3A + 1)][0], c[1][0]);
-                        c[1][1] = mma32(fa[kk % (MSST_B3_D3A + 1)][1], fb[kk % (MSST_B3_D3A + 1)][1], c[1][1]);
-                    });
-            } else {
-                swpipe<4, MSST_B3_D3A>(
-                    [&](int kk) {
-                        fa[kk % (MSST_B3_D3A + 1)][0] = lds_tr2(sm, p3_a1 + tr[0][0] + 2048 * kk, p3_a1 + tr[0][1] + 2048 * kk);
-                        fa[kk % (MSST_B3_D3A + 1)][1] = lds_tr2(sm, p3_a1 + tr[1][0] + 2048 * kk, p3_a1 + tr[1][1] + 2048 * kk);
-                        fb[kk % (MSST_B3_D3A + 1)][0] = lds_tr2(sm, p3_a2 + tr[0][0] + 2048 * kk, p3_a2 + tr[0][1] + 2048 * kk);
-                        fb[kk % (MSST_B3_D3A + 1)][1] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * kk, p3_a2 + tr[1][1] + 2048 * kk);
-                    },
-                    [&](int kk) {
-                        c[0][0] = mma32(fa[kk % (MSST_B3_D3A + 1)][0], fb[kk % (MSST_B3_D3A + 1)][0], c[0][0]);
-                        c[0][1] = mma32(fa[kk % (MSST_B3_D3A + 1)][0], fb[kk % (MSST_B3_D3A + 1)][1], c[0][1]);
-                        c[1][0] = mma32(fa[kk % (MSST_B3_D3A + 1)][1], fb[kk % (MSST_B3_D3A + 1)][0], c[1][0]);
-                        c[1][1] = mma32(fa[kk % (MSST_B3_D3A + 1)][1], fb[kk % (MSST_B3_D3A + 1)][1], c[1][1]);
-                    });
+            constexpr int D3 = MSST_B3_D3A;
+            s16x8 fa[D3 + 1][2], fb[D3 + 1][2];   // [slot][tile], D3 k-steps ahead
+            auto issue_b = [&](int kk) {
+                fb[kk % (D3 + 1)][0] = lds_tr2(sm, p3_a2 + tr[0][0] + 2048 * kk, p3_a2 + tr[0][1] + 2048 * kk);
+                fb[kk % (D3 + 1)][1] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * kk, p3_a2 + tr[1][1] + 2048 * kk);
+            };
+            auto issue_a = [&](int kk) {
+                if (pathX) {
+                    fa[kk % (D3 + 1)][0] = lds_r128(sm, a1 ^ (kk << 5));
+                    fa[kk % (D3 + 1)][1] = lds_r128(sm, (a1 ^ (kk << 5)) + 4096);
+                } else {
+                    fa[kk % (D3 + 1)][0] = lds_tr2(sm, p3_a1 + tr[0][0] + 2048 * kk, p3_a1 + tr[0][1] + 2048 * kk);
+                    fa[kk % (D3 + 1)][1] = lds_tr2(sm, p3_a1 + tr[1][0] + 2048 * kk, p3_a1 + tr[1][1] + 2048 * kk);
+                }
+            };
+#pragma unroll
+            for (int kk = 0; kk < D3; ++kk) issue_b(kk);
+            lds_barrier();   // B2
+            STAMP(5);
+            B3_PRIO(1);
+            R3_DUMP(2);
+#pragma unroll
+            for (int kk = 0; kk < D3; ++kk) issue_a(kk);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk + D3 < 4) { issue_a(kk + D3); issue_b(kk + D3); }
+                MSST_SCHED_FENCE();
+                c[0][0] = mma32(fa[kk % (D3 + 1)][0], fb[kk % (D3 + 1)][0], c[0][0]);
+                c[0][1] = mma32(fa[kk % (D3 + 1)][0], fb[kk % (D3 + 1)][1], c[0][1]);
+                c[1][0] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][0], c[1][0]);
+                c[1][1] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][1], c[1][1]);
+                MSST_SCHED_FENCE();
             }
             STAMP(11);
-            // dq / dk / dv also go to LDS, transposed ([d][row]), over the tile only this wave read above (k / q / dO)
+            s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) pa[dt][kk] = pk8(c[kk >> 1][dt], kk & 1);
+            // transposed 32-column fragment of a 96-wide tile in the C-layout row order: k row = 16 kk + 8 a + 4 hi + i / 4
+            const unsigned L4 = (4 * hi + (i >> 2)) * 192 + (((2 * u + b) ^ hi) << 4) + 8 * (i & 1);
+            unsigned tx[2];
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) tx[aa] = p3_x + (L4 ^ (aa << 5)) + 8 * aa * 192;
+            auto wgrad = [&]() {
+                s16x8 fx[MSST_B3_D3B + 1];   // step s = (kk, mt): transposed row fragment MSST_B3_D3B steps ahead
+                swpipe<12, MSST_B3_D3B>(
+                    [&](int st) {
+                        const int kk = st / 3, mt = st % 3;
+                        fx[st % (MSST_B3_D3B + 1)] = lds_tr2(sm, tx[0] + 3072 * kk + 64 * mt, tx[1] + 3072 * kk + 64 * mt);
+                    },
+                    [&](int st) {
+                        const int kk = st / 3, mt = st % 3;
+                        G[0][mt] = mma32(pa[0][kk], fx[st % (MSST_B3_D3B + 1)], G[0][mt]);
+                        G[1][mt] = mma32(pa[1][kk], fx[st % (MSST_B3_D3B + 1)], G[1][mt]);
+                    });
+            };
+            // dq | dk | dv also go to LDS, transposed ([d][row]), over the tile only this wave read above (k | q | dO)
             if (!roleO) {
                 const unsigned L7 = p3_a2 + l31 * 128 + (fz(l31) << 4) + 8 * hi;
 #pragma unroll
@@ -439,82 +478,56 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                         for (int q4 = 0; q4 < 4; ++q4)
                             lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + dt * 4096, pk4(c[ct][dt], q4));
             }
-            STAMP(13);
-            s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
+            // requests of the weight-gradient GEMM's shadow: the first phase-4 weight fragments (waves Q, K, V), the next tile's rows
+            const int l16 = l * 16;
+            // (wave O, which has no phase 4, requests one hot fragment six times: a definition on every path keeps the register
+            // allocator from shuffling the in-flight fragments of the other waves at the join)
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) pa[dt][kk] = pk8(c[kk >> 1][dt], kk & 1);
-            // phase-4 weights: requested now, used after the weight-gradient GEMM
-            if (!roleO) {
-                const int l16 = l * 16;
-#pragma unroll
-                for (int k12 = 0; k12 < 6; ++k12) w4[k12] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
-            }
-            STAMP(14);
+            for (int k12 = 0; k12 < 6; ++k12)
+                w4[k12] = ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
             tokn = load_rows(tile + gridDim.x, xnq, daq);
-            STAMP(12);
-            // transposed 32-column fragment of a 96-wide tile in the C-layout row order: k row = 16 kk + 8 a + 4 hi + i / 4
-            const unsigned L4 = (4 * hi + (i >> 2)) * 192 + (((2 * u + b) ^ hi) << 4) + 8 * (i & 1);
-            unsigned tx[2];
+            wgrad();
+            STAMP(6);
+            lds_barrier();   // B3
+            STAMP(7);
+            R3_DUMP(3);
+            // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
+            if (roleO) {
+                load_w1();   // the next tile's phase-1 weights
+            } else {
+                f32x16 c4[2];   // [row tile]: C[i = m][j = row]
+                c4[0] = zero16(); c4[1] = zero16();
+                s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
+                swpipe<12, MSST_B3_D4>(
+                    [&](int k12) {
+                        const int which = k12 >> 2, ks = k12 & 3;
+                        const int reg = which == 0 ? R3_K : which == 1 ? R3_Q : R3_DO;
+                        fb4[k12 % (MSST_B3_D4 + 1)][0] = lds_tr2(sm, reg + tr[0][0] + 2048 * ks, reg + tr[0][1] + 2048 * ks);
+                        fb4[k12 % (MSST_B3_D4 + 1)][1] = lds_tr2(sm, reg + tr[1][0] + 2048 * ks, reg + tr[1][1] + 2048 * ks);
+                    },
+                    [&](int k12) {
+                        c4[0] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][0], c4[0]);
+                        c4[1] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][1], c4[1]);
+                        if (k12 < 6)
+                            w4[k12] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + 6) >> 2) * (inner >> 4) + ((k12 + 6) & 3), l16);
+                        if (k12 == MSST_B3_W1AT) load_w1();   // the next tile's phase-1 weights, behind this phase's last weight request
+                    });
+                const unsigned L9 = R3_OUT + l31 * 192 + (fz2(l31) << 4) + 8 * hi + 64 * wave;
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa) tx[aa] = p3_x + (L4 ^ (aa << 5)) + 8 * aa * 192;
-            s16x8 fx[MSST_B3_D3B + 1];   // step s = (kk, mt): transposed row fragment MSST_B3_D3B steps ahead
-            swpipe<12, MSST_B3_D3B>(
-                [&](int st) {
-                    const int kk = st / 3, mt = st % 3;
-                    fx[st % (MSST_B3_D3B + 1)] = lds_tr2(sm, tx[0] + 3072 * kk + 64 * mt, tx[1] + 3072 * kk + 64 * mt);
-                },
-                [&](int st) {
-                    const int kk = st / 3, mt = st % 3;
-                    G[0][mt] = mma32(pa[0][kk], fx[st % (MSST_B3_D3B + 1)], G[0][mt]);
-                    G[1][mt] = mma32(pa[1][kk], fx[st % (MSST_B3_D3B + 1)], G[1][mt]);
-                });
+                for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) lds_w64(sm, (L9 ^ (q4 << 4)) + rt * 6144, pk4(c4[rt], q4));
+            }
+            store_rows(tokn, xnq, daq);
         }
-        STAMP(6);
-        lds_barrier();   // B3
-        STAMP(7);
-        R3_DUMP(3);
-        // rows of the next tile: XN and DA are dead from here on (the staging of phase 4 lives in V | P)
-        // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
-        if (!roleO) {
-            const int t_ = launder3(tid);
-            const int l = t_ & 63, l31 = l & 31, hi = l >> 5, i = l & 15, u = (l >> 4) & 1, b = (i >> 1) & 1, r1 = (i >> 3) & 1;
-            const unsigned Lt = (8 * hi + (i >> 2)) * 128 + (((2 * u + b) ^ ((r1 << 2) | (hi << 1) | hi)) << 4) + 8 * (i & 1);
-            unsigned tr[2][2];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa) tr[ct][aa] = (Lt ^ ((ct << 6) | (aa << 5))) + 512 * aa;
-            f32x16 c[2];   // [row tile]: C[i = m][j = row]
-            c[0] = zero16(); c[1] = zero16();
-            s16x8 fb[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
-            swpipe<12, MSST_B3_D4>(
-                [&](int k12) {
-                    const int which = k12 >> 2, ks = k12 & 3;
-                    const int reg = which == 0 ? R3_K : which == 1 ? R3_Q : R3_DO;
-                    fb[k12 % (MSST_B3_D4 + 1)][0] = lds_tr2(sm, reg + tr[0][0] + 2048 * ks, reg + tr[0][1] + 2048 * ks);
-                    fb[k12 % (MSST_B3_D4 + 1)][1] = lds_tr2(sm, reg + tr[1][0] + 2048 * ks, reg + tr[1][1] + 2048 * ks);
-                },
-                [&](int k12) {
-                    c[0] = mma32(w4[k12 % 6], fb[k12 % (MSST_B3_D4 + 1)][0], c[0]);
-                    c[1] = mma32(w4[k12 % 6], fb[k12 % (MSST_B3_D4 + 1)][1], c[1]);
-                    if (k12 < 6) w4[k12] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + 6) >> 2) * (inner >> 4) + ((k12 + 6) & 3), l * 16);
-                });
-            const unsigned L9 = R3_OUT + l31 * 192 + (fz2(l31) << 4) + 8 * hi + 64 * wave;
-#pragma unroll
-            for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) lds_w64(sm, (L9 ^ (q4 << 4)) + rt * 6144, pk4(c[rt], q4));
-        }
-        store_rows(tokn, xnq, daq);
         STAMP(8);
         lds_barrier();   // B4
         STAMP(9);
         B3_PRIO(0);
         R3_DUMP(4);
         // copy-out: whole rows of the staged result to this head's partial (buffer stores: a padding row gets an offset outside
-        // the descriptor and is dropped, so that every wave issues exactly three stores), then the next tile's phase-1 weights
+        // the descriptor and is dropped).  No barrier follows: phase 1 of the next tile reads XN / DA (published by barrier B4) and
+        // writes q | k | v | dO, none of which anybody reads any more; P | dS, where the rows are staged, are next written in phase 2
         {
             const int t_ = launder3(tid);
             const int tok_out = tok_sp(tile, rowmap[t_ >> 2]);
@@ -525,11 +538,6 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             const unsigned voff = tok_out < 0 ? 0x80000000u : (unsigned)tok_out * 192u + (t_ & 3) * 48;   // (+ 32 must not wrap)
 #pragma unroll
             for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 16 * j, 0, 0);
-            const int l16 = (t_ & 63) * 16;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
         }
         STAMP(10);
     }
@@ -546,7 +554,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 for (int r = 0; r < 16; ++r) {
                     const int d = 32 * dt + (r & 3) + 8 * (r >> 2) + 4 * hi, m = 32 * mt + l31;
                     if (roleO) slab[3 * 6144 + m * 64 + d] = G[dt][mt][r];
-                    else slab[wave * 6144 + d * 96 + m] = G[dt][mt][r];
+                    else slab[wave * 6144 + d * 96 + m] = wave < 2 ? G[dt][mt][r] * a.scale : G[dt][mt][r];   // dq, dk were kept / scale
                 }
     }
 }

@@ -106,9 +106,9 @@ class Engine:
         esz = 4 if self.prec == PREC_F32 else 2
         mats = [("wqkv", 3 * inner, D), ("wout", D, inner), ("w1", MLP, D), ("w2", D, MLP)]
         # bf16: three more copies in the 32-row x 16-k fragment packing of the round-3 attention backward (32x32x16 MFMAs)
-        mats32 = [("wqkv", 3 * inner, D, 0, "wqkv32"), ("wout", D, inner, 1, "woutT32"), ("wqkv", 3 * inner, D, 1, "wqkvT32")] \
+        mats32 = [("wqkv", 3 * inner, D, 0, "wqkv32", 1), ("wout", D, inner, 1, "woutT32", 1), ("wqkv", 3 * inner, D, 1, "wqkvT32", 2)] \
             if self.prec != PREC_F32 else []
-        per_layer = sum(2 * r * c for _, r, c in mats) + sum(r * c for _, r, c, _, _ in mats32)
+        per_layer = sum(2 * r * c for _, r, c in mats) + sum(r * c for _, r, c, _, _, _ in mats32)
         layers = self._layers()
         self._wbuf = torch.empty(per_layer * len(layers) * esz, dtype=torch.uint8, device=dev)
         base = self._wbuf.data_ptr()
@@ -129,10 +129,10 @@ class Engine:
                     off += r * c
                     j += 1
                     maxel = max(maxel, r * c)
-            for name, r, c, tr, field in mats32:
+            for name, r, c, tr, field, pack in mats32:
                 dst = base + off * esz
                 jobs[j].src, jobs[j].dst, jobs[j].rows, jobs[j].cols = self.fp.ptr(f"{sname}.{l}.{name}"), dst, r, c
-                jobs[j].transpose, jobs[j].pack = tr, 1
+                jobs[j].transpose, jobs[j].pack = tr, pack
                 setattr(bw, field, dst)
                 off += r * c
                 j += 1

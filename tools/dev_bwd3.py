@@ -126,18 +126,24 @@ def main():
         masks = model.draw_masks(cfg["B"])
         out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=(0.1, 5))
         dy = torch.randn_like(out["enc_out"]) * 1e-3
-        for flag in (0, 32, 0, 32):
-            os.environ["MSST_DBG"] = str(flag)
-            eng.lib.msst_profile_enable(1)
-            for _ in range(5):
-                eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=(0.1, 5))
-            torch.cuda.synchronize()
-            n = eng.lib.msst_profile_kernels()
-            tot = (ctypes.c_double * n)()
-            cnt = (ctypes.c_long * n)()
-            eng.lib.msst_profile_collect(tot, cnt)
-            eng.lib.msst_profile_enable(0)
-            print("flag", flag, {eng.lib.msst_profile_name(i).decode(): round(1e3 * tot[i] / max(cnt[i], 1), 1) for i in range(n) if cnt[i]})
+        res = {0: [], 32: []}
+        for rnd in range(4):
+            for flag in (0, 32):
+                os.environ["MSST_DBG"] = str(flag)
+                eng.lib.msst_profile_enable(1)
+                for _ in range(8):
+                    eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=(0.1, 5))
+                torch.cuda.synchronize()
+                n = eng.lib.msst_profile_kernels()
+                tot = (ctypes.c_double * n)()
+                cnt = (ctypes.c_long * n)()
+                eng.lib.msst_profile_collect(tot, cnt)
+                eng.lib.msst_profile_enable(0)
+                d = {eng.lib.msst_profile_name(i).decode(): round(1e3 * tot[i] / max(cnt[i], 1), 1) for i in range(n) if cnt[i]}
+                if rnd:
+                    res[flag].append(d)
+        for flag in (0, 32):
+            print("flag", flag, {k: min(r[k] for r in res[flag]) for k in res[flag][0]})
         os.environ["MSST_DBG"] = "0"
 
 
