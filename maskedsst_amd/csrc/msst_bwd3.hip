@@ -223,7 +223,6 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #define R3_DUMP(stage) do { } while (0)
 #endif
         STAMP(0);
-        STAMP(1);
         B3_PRIO(1);
         R3_DUMP(0);
         // ---------------- phase 1: q | k | v | dO = rows . W^T  (C[i = channel][j = row], stored [row][channel]) ----------------
@@ -443,7 +442,6 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 c[1][1] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][1], c[1][1]);
                 MSST_SCHED_FENCE();
             }
-            STAMP(11);
             s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)

@@ -40,6 +40,11 @@
 #ifndef MSST_F2_PRIO
 #define MSST_F2_PRIO 0
 #endif
+#ifndef MSST_F2_RELOAD
+#define MSST_F2_RELOAD 1   // weight-fragment offsets are re-derived on the scalar unit where they are used (the head / wave-role indices pass
+                           // through an opaque scalar register): hoisted out of the tile loop they were 178 SGPRs spilled to VGPR lanes,
+                           // i.e. ~190 v_readlane per wave and tile in a kernel whose limiter is the VALU stream
+#endif
 #ifndef MSST_F2_SKIP
 #define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
 #endif
@@ -69,6 +74,13 @@ struct Fwd2Smem {
     float2 st[8][16];                     // LN2 partial statistics (mean, M2 over 48 features): [wave][row in tile]
     elem hb[64][LDH];                     // GELU(W1 .) of the MLP
 };
+
+__device__ __forceinline__ int sopaque(int v) {
+#if MSST_F2_RELOAD
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
 
 __device__ __forceinline__ frag pack2(f32x4 lo, f32x4 hi) {
     const s16x4 a = f2bf4(lo), b = f2bf4(hi);
@@ -258,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, h, voff);   // past pair 17: the next tile's first pairs
+                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, sopaque(h), voff);   // past pair 17: the next tile's first pairs
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -280,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                             ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                         }
                         __builtin_amdgcn_sched_barrier(0);
-                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, h, voff);   // past pair 17: the next tile's first pairs
+                        load_pair(next_pair(pi), ring[pi % NR], wqkv, wout, H, sopaque(h), voff);   // past pair 17: the next tile's first pairs
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     vA[2 * mm][0] = pack2(cl[0], cl[1]);     vA[2 * mm][1] = pack2(cl[2], cl[3]);
@@ -415,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * mh + i) * 16, (8 * kh + s8) * 32);
+            for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
         lds_barrier();   // O complete
         STAMP(11);
         // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------

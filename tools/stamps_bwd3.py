@@ -18,7 +18,8 @@ out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
 dy = torch.randn_like(out["enc_out"]) * 1e-3
 buf = torch.zeros(512, dtype=torch.int64, device="cuda")
 assert eng.lib.msst_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0, "build with --stamps"
-names = ["top", "B0", "phase 1", "B1", "phase 2", "B2", "phase 3", "B3", "phase 4", "B4", "copy-out"]
+names = ["top", "phase 1", "B1", "phase 2", "B2", "phase 3", "B3", "phase 4", "B4", "copy-out"]
+IDX = [0, 2, 3, 4, 5, 6, 7, 8, 9, 10]
 B, S, N, H = cfg["B"], eng.S, eng.N, eng.enc.heads
 ntok = B * S * N
 acts, x1s = out["acts"], out["x1s"]
@@ -40,7 +41,6 @@ for i in (0, 1):
                 eng.prec | _kernel_flags(), drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
             torch.cuda.synchronize()
         s = buf.cpu().numpy()
-        d = [int(s[k + 1] - s[k]) for k in range(10)]
-        print(f"{sname} wave {'QKVO'[wave]}: total {int(s[10] - s[0]):6d} | " + " ".join(f"{n}:{v}" for n, v in zip(names[1:], d)) +
-              f" | p3a:{int(s[11] - s[5])} st:{int(s[13] - s[11])} pack+w4:{int(s[14] - s[13])} rows:{int(s[12] - s[14])} p3b:{int(s[6] - s[12])}")
+        d = [int(s[IDX[k + 1]] - s[IDX[k]]) for k in range(len(IDX) - 1)]
+        print(f"{sname} wave {'QKVO'[wave]}: total {int(s[10] - s[0]):6d} | " + " ".join(f"{n}:{v}" for n, v in zip(names[1:], d)))
 os.environ["MSST_DBG"] = "0"
