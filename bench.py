@@ -70,6 +70,11 @@ def main():
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)   # internal: run ONE cpu_baseline leg at this thread count
     ap.add_argument("--no-pipeline", action="store_true",
                     help="skip the second timed region that feeds the loop from SyntheticCubeLoader (input pipeline inclusive rate)")
+    ap.add_argument("--cu-thief", type=int, default=0,
+                    help="run N occupancy-probe workgroups (msst_debug_cu_thief: each holds one CU slot no MFMA workgroup fits beside) "
+                         "on a side stream for the duration of every timed step -- what RCCL's channel workgroups take from the "
+                         "backward under data parallelism, measured on one GPU")
+    ap.add_argument("--thief-us", type=float, default=25000.0, help="how long each probe launch holds its CUs (microseconds)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single process, but through the data-parallel path: a one-rank RCCL process group, bucket hooks, "
                          "all-reduce calls, mean inside AdamW (MSST_FORCE_DP=1); for traces of the DP wiring on a 1-GPU box")
@@ -157,9 +162,18 @@ def main():
     if prof:
         lib.msst_profile_enable(1)
     torch.cuda.synchronize()
+    thief_stream = torch.cuda.Stream() if args.cu_thief > 0 else None
+    thief_sink = torch.zeros(4, dtype=torch.int32, device=dev) if args.cu_thief > 0 else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        if thief_stream is not None:
+            # one probe launch per step, sized to outlast it; the next step's probe queues behind it on the side stream
+            thief_stream.wait_stream(torch.cuda.current_stream())
+            lib.msst_debug_cu_thief(args.cu_thief, int(args.thief_us), ctypes.c_void_p(thief_sink.data_ptr()),
+                                    ctypes.c_void_p(thief_stream.cuda_stream))
         loss = step()
+        if thief_stream is not None:
+            torch.cuda.current_stream().wait_stream(thief_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -224,6 +238,8 @@ def main():
         }
         if args.force_dp:
             out["forced_dp"] = True
+        if args.cu_thief:
+            out["cu_thief"] = {"workgroups": args.cu_thief, "hold_us": args.thief_us}
         if pipe is not None:
             out["pipeline_inclusive"] = pipe
         if kernels:
@@ -238,7 +254,7 @@ def main():
             # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own); read from the
             # committed summary of the PMC passes of this same command and labelled as such
             traffic, traffic_source = None, None
-            for tf in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for tf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                     if B == 256 and args.bands == 200 and args.depth == 12 and args.precision == "bf16" and dom in tj["kernels"]:
@@ -247,13 +263,39 @@ def main():
                         break
                 except Exception:
                     continue
+            peak_measured = None
+            hbm_measured = None
+            try:
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_peak_microbench.json")))
+                peak_measured = pm.get("mfma_bf16_32x32x16_tflops") if args.precision == "bf16" else None
+                hbm_measured = pm.get("hbm_copy_gbps")
+            except Exception:
+                pass
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
+                               "peak_measured": peak_measured,
+                               "peak_measured_source": "profiles/r03_peak_microbench.json (tools/peak_microbench.hip on an MI355X of this pool: "
+                                                       "back-to-back 32x32x16 bf16 MFMAs on random operands; committed, not measured in this run)",
+                               "frac_of_measured_peak": round(achieved / peak_measured, 4) if peak_measured else None,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": traffic_source,
                                "avg_launch_us": round(cand[dom]["avg_us"], 2),
                                "algorithmic_gflop_per_launch": round(fl / 1e9, 3)}
             out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
                                   "share": round(v["total_ms"] / (1e3 * elapsed), 4)} for k, v in kernels.items()}
+            # HBM-bound kernels: GB/s = committed PMC bytes per launch (same command) / this run's average launch time
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+                times = dict(survey)
+                times.update(kernels)
+                if B == 256 and args.bands == 200 and args.depth == 12 and args.precision == "bf16":
+                    out["hbm_bound_kernels"] = {
+                        k: {"gbps": round(tj[k]["hbm_bytes_per_launch"] / (times[k]["avg_us"] * 1e-6) / 1e9, 0),
+                            "avg_us": round(times[k]["avg_us"], 2), "bytes_per_launch": tj[k]["hbm_bytes_per_launch"]}
+                        for k in ("block_bwd_ln1", "block_bwd_mlp", "tokenize_fwd", "tokenize_bwd", "head_bwd", "adamw", "reduce_slabs")
+                        if k in tj and k in times}
+                    out["hbm_peak"] = {"nominal_gbps": 8000, "measured_copy_gbps": hbm_measured}
+            except Exception:
+                pass
             if survey and not args.profile_all:   # untimed warmup steps, every kernel bracketed
                 out["warmup_survey"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"]}
                                         for k, v in survey.items()}
@@ -315,18 +357,22 @@ def cpu_baseline(args):
     """The CPU oracle (oracle/: plain-PyTorch fp32 restatement of the reference, pinned to the reference by
     tests/golden) doing the same training step -- fwd + autograd bwd + value clamp + torch AdamW, training-mode dropout
     with the same p as the GPU leg (Bernoulli masks drawn per step like nn.Dropout does) -- on this box's host cores, on
-    a bounded sample.  Two legs, as SURVEY 8d / BASELINE.md section 4 ask: (i) 4 threads, the cap the reference imposes on
-    itself (reference pretrain.py:4-9), (ii) every logical core.  Each leg runs in a child process under a wall-clock
-    limit: with hundreds of threads the many small ops of this model can take minutes per step (measured on a 256-thread
-    box: 354 s for ONE batch-8 step against 2.7 s at 4 threads), and the default bench must finish within minutes; a leg
-    that does not finish in time is reported as such.  `value` is the fastest leg that finished."""
+    a bounded sample.  A short thread-count sweep (SURVEY 8d / BASELINE.md section 4 ask for the reference's 4-thread cap and
+    an all-core-class number): 4 threads (reference pretrain.py:4-9), 16, and a quarter of the logical cores.  Each leg runs in
+    a child process under a wall-clock limit, so that the default bench finishes within minutes; `value` is the fastest leg
+    that finished, `cores` its thread count."""
     import subprocess
     ncpu = os.cpu_count() or 4
     legs = []
-    for threads, limit in ((4, 90), (ncpu, 75)) if ncpu != 4 else ((4, 90),):
+    # 4 threads = the reference's own cap (pretrain.py:4-9); 16; half the physical cores (logical / 4 with SMT-2).  A leg that
+    # cannot finish warm-up + one timed step inside its limit is reported as such (oversubscription on thousands of small ops:
+    # ONE batch-8 step took 354 s at 256 threads on a box of this pool).
+    sweep = sorted({4, min(16, ncpu), max(4, ncpu // 4)})
+    for threads in sweep:
+        limit = 40 if threads == 4 else 25
         cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", str(threads), "--bands", str(args.bands), "--depth",
                str(args.depth), "--heads", str(args.heads), "--cpu-batch", str(args.cpu_batch), "--dropout", str(args.dropout),
-               "--cpu-budget", str(args.cpu_budget)]
+               "--cpu-budget", str(min(args.cpu_budget, 10.0))]
         env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
         t0 = time.perf_counter()
         try:
@@ -343,8 +389,8 @@ def cpu_baseline(args):
     return {"value": best["value"], "unit": "samples/s", "cores": best["threads"], "kind": "port", "legs": legs,
             "sample": f"bounded sample: up to 8 steps / {args.cpu_budget:.0f} s per leg of batch {args.cpu_batch} (same model/config as the GPU "
                       f"leg: {args.bands} bands, depth {args.depth}x2, fwd+bwd+clamp+AdamW, dropout {args.dropout} in training mode), torch "
-                      f"{torch.__version__} CPU fp32; legs at 4 threads (the reference's own cap, pretrain.py:4-9) and at all {ncpu} "
-                      f"logical cores, each in a child process under a wall-clock limit; value = the fastest leg that finished"}
+                      f"{torch.__version__} CPU fp32; legs at {sweep} threads of {ncpu} logical cores (4 = the reference's own cap, "
+                      f"pretrain.py:4-9), each in a child process under a 25-40 s wall-clock limit; value = the fastest leg that finished"}
 
 
 if __name__ == "__main__":

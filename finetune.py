@@ -17,7 +17,7 @@ import yaml
 
 from maskedsst_amd import ViTSpatialSpectral
 from maskedsst_amd.config import Dotdict
-from maskedsst_amd.utils import load_checkpoint, train_step
+from maskedsst_amd.utils import get_spectral_pos_embedding, load_checkpoint, train_step
 
 SEED = 5
 
@@ -29,14 +29,21 @@ def get_finetune_config(path, general_path, seed, device):
     hp.update(general["data"][hp["dataset"]])
     hp.update(general["transformer"])
     hp["seed"], hp["device"] = seed, device
-    hp["spectral_pos"] = torch.arange(hp["n_bands"] // hp["band_patch_size"])
+    if hp["method_name"] != "ViTSpatialSpectral":
+        raise NotImplementedError("only the ViTSpatialSpectral method is built (the DeepHyperX 'li' baseline is out of scope)")
+    if hp["dataset"] == "houston2018":
+        # the two sensors' band-centre tables live with the (out of scope) readers: the config carries the lookup's result
+        hp["spectral_pos"] = torch.as_tensor(hp["spectral_pos"])
+        assert len(hp["spectral_pos"]) == hp["n_bands"] // hp["band_patch_size"]
+    else:
+        hp["spectral_pos"] = get_spectral_pos_embedding(hp["dataset"], hp["n_bands"], hp["band_patch_size"])
     hp["patch_sub"] = 1 if (hp["pixelwise"] and hp["image_size"] % 2 == 0) else 0
     return Dotdict(hp)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("dataset", nargs="?", default="enmap", choices=["enmap"])
+    ap.add_argument("dataset", nargs="?", default="enmap", choices=["enmap", "houston2018"])   # reference finetune.py:42-46
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--batch-size", type=int, default=None)
     ap.add_argument("--checkpoint", default=None)
@@ -75,6 +82,8 @@ def main():
     t0 = time.time()
     for step in range(1, args.steps + 1):
         img = torch.randn(config.batch_size, config.n_bands, 64, 64, generator=gen)
+        if config.dataset == "houston2018":
+            img[:, 48:] = 0.0   # 48 real bands zero padded to 50 (reference src/data_houston2018.py:268-269)
         label = torch.randint(-1, config.n_classes, (config.batch_size, 64, 64), generator=gen)
         loss, acc, _ = train_step(img, label, model, config, device, criterion, optimizer)
         if step % config.logging_freq == 0:

@@ -184,6 +184,11 @@ int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * the launch count since enable / the previous collect.  Thread-safe (mutex); meant for bench.py.
  * msst_debug_stamps: kernel-study builds (-DMSST_STAMPS) only; returns MSST_ERR_UNSUPPORTED otherwise. */
 int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tools/stamps.py */);
+/* Occupancy probe (diagnostic, bench.py --cu-thief): nblocks workgroups that only hold a CU slot each (256 threads, the full
+ * register budget of two waves per SIMD and 64 KB of LDS, so that no MFMA workgroup fits beside one) for `microseconds`,
+ * enqueued on `stream`; sink: 4 bytes of device scratch.  Stands in for the channel workgroups of an RCCL collective when
+ * the overlap of the gradient all-reduce with the backward is studied on ONE GPU. */
+int msst_debug_cu_thief(int nblocks, int microseconds, void* sink, void* stream);
 int msst_profile_enable(int on);
 /* restrict the event pairs to the kernel ids whose bit is set (default: all); each pair costs ~10 us of stream time */
 int msst_profile_select(unsigned long long mask);

@@ -58,6 +58,7 @@ _SIGS = {
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, c_float,
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),
+    "msst_debug_cu_thief": (c_int, [c_int, c_int, _P, _P]),
     "msst_profile_enable": (c_int, [c_int]),
     "msst_profile_select": (c_int, [ctypes.c_ulonglong]),
     "msst_profile_kernels": (c_int, []),

@@ -158,6 +158,10 @@ int msst_debug_stamps(void* buf) {
 #endif
 }
 
+int msst_debug_cu_thief(int nblocks, int microseconds, void* sink, void* stream) {
+    return fail(launch_cu_thief(nblocks, microseconds, (unsigned*)sink, (hipStream_t)stream), "msst_debug_cu_thief");
+}
+
 int msst_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (on) { g_prof.clear(); g_pool_next = 0; }

@@ -60,4 +60,31 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
     return (int)hipGetLastError();
 }
 
+// CU-occupancy probe for the data-parallel overlap: `nblocks` workgroups that do nothing but hold their CU
+// slot (a full register budget, so that nothing else fits beside them -- like a communication kernel's channel
+// workgroups) until `us` microseconds of the constant-rate device clock have passed.  bench.py --cu-thief runs it on a
+// side stream under the backward to measure what the static grids of the MFMA kernels lose to RCCL's channels.
+__global__ __launch_bounds__(256, 2) void cu_thief_kernel(unsigned long long ticks, unsigned* sink) {
+    const unsigned long long t0 = wall_clock64();
+    unsigned acc = threadIdx.x;
+    while (wall_clock64() - t0 < ticks) {
+        acc = acc * 1664525u + 1013904223u;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    if (acc == 0x12345u) sink[0] = acc;   // never true in practice; keeps the loop alive
+}
+
+int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st) {
+    if (nblocks < 1 || us < 1) return 0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_thief_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    // wall_clock64 ticks at 100 MHz on gfx9
+    hipLaunchKernelGGL(cu_thief_kernel, dim3(nblocks), dim3(256), 64 * 1024, st, (unsigned long long)us * 100ull, sink);
+    return (int)hipGetLastError();
+}
+
 }  // namespace msst

@@ -74,6 +74,17 @@ class Engine:
     def P(self):
         return self.enc.pixels_per_patch
 
+    def reserve_cus(self, n, total=256):
+        """Leave ``n`` of the chip's CUs free of backward workgroups (data parallel: RCCL's channels).  The attention
+        backward runs heads x chunks workgroups at two per CU, the row-wise kernels one (two for the MLP half) per grid
+        row; explicit MSST_ATTN_CHUNKS / MSST_BWD_GRID settings win."""
+        n = max(0, min(int(n), total - 8))
+        H = max(1, int(self.enc.heads))
+        if "MSST_ATTN_CHUNKS" not in os.environ:
+            self.attn_chunks = max(1, (2 * (total - n)) // H)
+        if "MSST_BWD_GRID" not in os.environ:
+            self.grid_rows = total - n
+
     def set_precision(self, name):
         prec = _prec_of(name)
         if prec != self.prec:
@@ -436,8 +447,25 @@ class Engine:
         return self.tokenize(img, None, with_pos=False)
 
     def features(self, img):
-        """forward_features (reference :518-534): tokenize + pos (+ embedding dropout in training mode) -> transformer"""
-        pe = float(self.enc.emb_dropout_p) if self.enc.training else 0.0
+        """forward_features (reference :518-534): tokenize + pos (+ embedding dropout in training mode) -> transformer.
+
+        Differentiable like the reference's: when gradients are enabled and any encoder parameter requires one, the result is
+        composed of the two autograd entry points (``embed_patches`` and ``transformer``) with the position add and the
+        embedding dropout as ordinary torch ops in between -- exactly what the reference's own SimMIM wrapper does with this
+        encoder -- so a custom head trained on these features trains the encoder too.  Otherwise (eval / no_grad) one fused
+        tokenizer launch does embed + position + dropout."""
+        enc = self.enc
+        params = [q for _, q in self.trainable()]
+        if torch.is_grad_enabled() and any(q.requires_grad for q in params):
+            self._require_cuda(img)
+            patches = enc.to_patch_embedding.to_patch(img.contiguous().float())
+            tokens = self.embed_patches(patches).reshape(img.shape[0], -1, D)
+            pos = enc.get_pos_embeddings() if enc.spectral_pos_embed else enc.pos_embedding[:, :tokens.shape[1]]
+            tokens = tokens + pos
+            if enc.training and float(enc.emb_dropout_p) > 0:
+                tokens = torch.nn.functional.dropout(tokens, p=float(enc.emb_dropout_p), training=True)
+            return self.transformer(tokens)
+        pe = float(enc.emb_dropout_p) if enc.training else 0.0
         emb_drop = (pe, int(torch.randint(0, 2 ** 31 - 1, (1,)).item())) if pe > 0 else (0.0, 0)
         x0 = self.tokenize(img, None, with_pos=True, emb_drop=emb_drop)
         with torch.no_grad():

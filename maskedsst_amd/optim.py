@@ -64,7 +64,9 @@ class BucketReducer:
         else:  # non-contiguous: flush what we have, start a new run
             self._flush()
             self.pending = (s, e)
-        if (self.pending[1] - self.pending[0]) * self.flat.element_size() >= self.bucket_bytes:
+        # the LAST bucket of the backward (the tokenizer's) goes out from its own hook: left to finish(), its all-reduce would
+        # start only when the host gets there and sit fully exposed in front of the optimizer step
+        if (self.pending[1] - self.pending[0]) * self.flat.element_size() >= self.bucket_bytes or name == self.order[-1]:
             self._flush()
 
     def _flush(self):
@@ -145,6 +147,11 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise RuntimeError(f"FusedAdamW.step(): parameter {name!r} has no gradient from the HIP backward of "
                                    "this step (call loss.backward() first; gradients must be the flat-buffer views)")
         self._checked_flat = grad.data_ptr()
+        # cheap per-step guard on one sentinel per end of the buffer: a later step whose .grad is not a flat-buffer view any
+        # more (e.g. hooks that replace gradients) must not be applied from stale buffer contents
+        for name, p in (named[0], named[-1]):
+            if not (lo <= p.grad.data_ptr() < hi):
+                raise RuntimeError(f"FusedAdamW.step(): the gradient of {name!r} is no view of the flat gradient buffer")
         g = self.param_groups[0]
         self._step += 1
         n = eng.fp.n_trainable
@@ -157,7 +164,9 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def state_dict(self):
         d = super().state_dict()
-        d["fused"] = dict(step=self._step, m=self._m, v=self._v)
+        # clones: an in-memory snapshot must not keep changing as training continues
+        d["fused"] = dict(step=self._step, m=None if self._m is None else self._m.clone(),
+                          v=None if self._v is None else self._v.clone())
         return d
 
     def load_state_dict(self, state_dict):
@@ -165,15 +174,16 @@ class FusedAdamW(torch.optim.Optimizer):
         (a resumed run continues the bias correction where it stopped instead of restarting at step 0)."""
         state_dict = dict(state_dict)
         fused = state_dict.pop("fused", None)
-        super().load_state_dict(state_dict)
+        # validate everything BEFORE touching any state: a failed load must leave the optimizer as it was
         if fused is None:
             raise KeyError("state dict has no 'fused' entry: it was not produced by FusedAdamW.state_dict()")
         eng = self.model.engine()
         flat, _, m, v = self._state(eng)
+        if fused["m"] is not None and (fused["m"].numel() != m.numel() or fused["v"] is None or fused["v"].numel() != v.numel()):
+            raise ValueError(f"fused moments have {fused['m'].numel()} elements, the model needs {m.numel()}")
+        super().load_state_dict(state_dict)
         self._step = int(fused["step"])
         if fused["m"] is not None:
-            if fused["m"].numel() != m.numel():
-                raise ValueError(f"fused moments have {fused['m'].numel()} elements, the model needs {m.numel()}")
             m.copy_(fused["m"].to(m.device))
             v.copy_(fused["v"].to(v.device))
         else:
@@ -192,4 +202,9 @@ def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
     model.dp_world = dist.get_world_size(group) if dist.is_initialized() else 1
     red = BucketReducer(eng.fp.grad, eng.fp.buckets, group=group, bucket_bytes=bucket_bytes)
     eng.bucket_hook = red.bucket_ready
+    # RCCL's channel workgroups need CUs of their own while the backward runs: the persistent grids of the backward kernels are
+    # sized so that every workgroup is resident on the CUs left (a static 2-per-CU grid that loses CUs runs its displaced
+    # workgroups as a second wave behind the others; profiles/r03_dp_cu_contention.jsonl)
+    if model.dp_world > 1 or os.environ.get("MSST_FORCE_DP", "0") == "1":
+        eng.reserve_cus(int(os.environ.get("MSST_DP_RESERVE_CUS", "16")))
     return red

@@ -42,10 +42,11 @@ def get_pos_for_spectral_embedding(spectral_patch_depth, wavelengths, reference_
 
 def get_spectral_pos_embedding(dataset, n_bands, band_patch_size, wavelengths=None, reference_wavelengths=None):
     """reference src/utils.py:415-429: positions of a dataset's spectral tokens in the pre-training sensor's spectral
-    sequence -- the identity for EnMAP-derived data (worldcover / dfc / enmap), the nearest-block lookup for
+    sequence -- the identity for the EnMAP-derived label sets (worldcover / dfc), the nearest-block lookup for
     Houston2018 (its band-centre table and the reference sensor's are data the caller supplies; the readers that carry
-    them are out of scope here)."""
-    if dataset in ("worldcover", "dfc", "enmap"):
+    them are out of scope here).  Any other name raises, as in the reference (dataset: enmap is a pre-training set and
+    has no finetune labels there either)."""
+    if dataset in ("worldcover", "dfc"):
         return torch.arange(n_bands // band_patch_size)
     if dataset == "houston2018":
         if wavelengths is None or reference_wavelengths is None:

@@ -118,8 +118,10 @@ def main():
                                grad_clamp=1.0 if config.clip_grad_norm else 0.0)
     if config.scheduler == "cosine":       # reference src/utils.py:47-59
         scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=50, eta_min=0, last_epoch=-1)
-    else:
+    elif config.scheduler == "ReduceLROnPlateau":
         scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=0.9, patience=5)
+    else:   # the stepping below tests the same two names: anything else would train at a constant rate without a word
+        raise ValueError(f"unknown scheduler {config.scheduler!r} (reference src/utils.py:47-59 knows ReduceLROnPlateau and cosine)")
     reducer = attach_data_parallel(model) if world > 1 else None
 
     # synthetic standardised tiles [bands, 64, 64] (per-band N(0,1), like StandardizeEnMAP output), cropped per batch

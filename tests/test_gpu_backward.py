@@ -119,12 +119,14 @@ def test_param_grads_bf16(cfg):
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
 @pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-def test_attn_bwd_kernels_agree(cfg, drop, monkeypatch):
-    """The tuned bf16 attention backward (msst_bwd2.hip; fed with the LN1 rows saved by the forward and the pre-dropped
-    bf16 da rows left by the MLP half) against the template kernel it was derived from (msst_bwd.hip, MSST_DBG=16;
-    re-reads x / dx1, renormalises, applies the to_out dropout itself): same bf16 operands and the same dropout masks up
-    to summation order, so every gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and
-    spectral tiles, 64- and short-sequence masking, padding rows, with and without dropout)."""
+@pytest.mark.parametrize("tuned", [0, 32], ids=["r3", "r2"])
+def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
+    """The tuned bf16 attention backward kernels -- round 3 (msst_bwd3.hip: one GEMM per wave, 32x32x16 MFMAs, swizzled LDS
+    tiles; the default) and round 2 (msst_bwd2.hip, MSST_DBG=32), both fed with the LN1 rows saved by the forward and the
+    pre-dropped bf16 da rows left by the MLP half -- against the template kernel (msst_bwd.hip, MSST_DBG=16; re-reads
+    x / dx1, renormalises, applies the to_out dropout itself): same bf16 operands and the same dropout masks up to summation
+    order, so every gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and spectral tiles, 64- and
+    short-sequence masking, padding rows, a partial last tile, with and without dropout)."""
     model, params, x = build_product(cfg, precision="bf16", device="cuda")
     eng = model.engine()
     masks = model.draw_masks(cfg["B"])
@@ -136,6 +138,7 @@ def test_attn_bwd_kernels_agree(cfg, drop, monkeypatch):
         torch.cuda.synchronize()
         return dx0.clone(), eng.fp.grad.clone()
 
+    monkeypatch.setenv("MSST_DBG", str(tuned))
     dx_new, g_new = run()
     monkeypatch.setenv("MSST_DBG", "16")
     dx_old, g_old = run()
@@ -151,5 +154,5 @@ def test_attn_bwd_kernels_agree(cfg, drop, monkeypatch):
         worst = max(worst, e)
         if not e < 3.2e-3:
             bad.append((name, e))
-    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), dx=e_dx, worst_grad=worst)
+    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), kernel="r2" if tuned else "r3", dx=e_dx, worst_grad=worst)
     assert not bad, bad

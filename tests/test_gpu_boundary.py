@@ -14,7 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from conftest import oracle_cfg_from, seed_all
-from util import build_product, relerr, record
+from util import rel_l2, build_product, relerr, record
 
 pytestmark = pytest.mark.gpu
 
@@ -79,6 +79,79 @@ def test_autograd_through_encoder_entry_points(cfg):
     reference_style_simmim_loss(model, x.cuda(), masks).backward()
 
 
+def test_forward_features_is_differentiable_like_the_reference():
+    """forward_features (reference vit_spatial_spectral.py:518-534) in training mode must carry gradients to the
+    encoder -- a custom head trained on it would otherwise train with a silently frozen encoder.  Every encoder gradient of
+    mean(features^2) against the oracle's autograd of the same function."""
+    from oracle import encoder_embed, transformer_forward
+    from oracle.model import pos_table
+    from maskedsst_amd import ViTSpatialSpectral
+    cfg = dict(bands=50, depth=2, B=3)
+    ocfg = oracle_cfg_from(cfg)
+    seed_all(5)
+    enc = ViTSpatialSpectral(image_size=8, spatial_patch_size=1, spectral_patch_size=10, num_classes=8, dim=96, depth=2, heads=8,
+                             mlp_dim=64, dropout=0.0, emb_dropout=0.0, channels=50, spectral_pos_embed=False,
+                             spectral_pos=torch.arange(5), blockwise_patch_embed=True, precision="fp32")
+    params = {"encoder." + k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    x = torch.randn(3, 50, 8, 8)
+    _, tok = encoder_embed(params, x, ocfg)
+    ref = transformer_forward(params, tok + pos_table(params, ocfg), ocfg)
+    ref.square().mean().backward()
+    enc = enc.cuda().train()
+    feats = enc.forward_features(x.cuda())
+    assert feats.requires_grad and relerr(feats, ref) < 1e-4
+    feats.square().mean().backward()
+    torch.cuda.synchronize()
+    bad = []
+    for name, q in enc.named_parameters():
+        g_ref = params["encoder." + name].grad
+        if g_ref is None:
+            continue
+        assert q.grad is not None, name
+        e = relerr(q.grad, g_ref)
+        if not e < 2e-4:
+            bad.append((name, e))
+    assert not bad, bad
+    enc.eval()
+    with torch.no_grad():
+        assert relerr(enc.forward_features(x.cuda()), ref) < 1e-4     # the fused eval path agrees
+
+
+def test_cu_thief_probe_does_not_change_results():
+    """bench.py --cu-thief (SURVEY 8e evidence on one GPU): occupancy-probe workgroups held on a side stream during a step
+    take CUs away from the backward's persistent grids; the step's numbers must be unaffected, and a grid sized for the CUs
+    left (Engine.reserve_cus, what attach_data_parallel selects) gives the same gradients as the default grid."""
+    import ctypes
+    cfg = dict(bands=200, depth=1, B=16)
+    model, _, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    xc = x.cuda()
+
+    def grads():
+        for q in model.parameters():
+            q.grad = None
+        loss = model(xc, masks=masks)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.item(), eng.fp.grad.clone()
+
+    l0, g0 = grads()
+    side = torch.cuda.Stream()
+    sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+    rc = eng.lib.msst_debug_cu_thief(32, 20000, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0
+    l1, g1 = grads()
+    side.synchronize()
+    assert l1 == l0 and torch.equal(g0, g1)
+    chunks, rows = eng.attn_chunks, eng.grid_rows
+    eng.reserve_cus(16)
+    assert eng.attn_chunks * eng.enc.heads == 2 * (256 - 16) and eng.grid_rows == 240
+    l2, g2 = grads()
+    eng.attn_chunks, eng.grid_rows = chunks, rows
+    assert l2 == l0 and rel_l2(g2, g0) < 1e-5       # another partition of the tiles: same sums, other summation order
+
+
 def test_transformer_forward_no_grad_matches_autograd_path():
     model, _, x = build_product(dict(bands=50, depth=2, B=2), precision="bf16", device="cuda")
     enc = model.encoder
@@ -103,15 +176,19 @@ def make_batch(gen, B, bands, n_classes, amp=1.0):
     return img, torch.where(drop, torch.full_like(label, -1), label)
 
 
-def test_config5_short_finetune_accuracy_vs_oracle():
-    """BASELINE config 5 ("accuracy vs CPU ref"): 30 Adam steps with the finetune hyper-parameters of the reference
+@pytest.mark.parametrize("shape", [dict(bands=80, depth=2, B=8, steps=30), dict(bands=200, depth=4, B=4, steps=24)],
+                         ids=["80b-L2", "shipped-200b-L4"])
+def test_config5_short_finetune_accuracy_vs_oracle(shape):
+    """BASELINE config 5 ("accuracy vs CPU ref"): Adam steps with the finetune hyper-parameters of the reference
     (finetune.py:110-134: lr 5e-4 body / 5e-3 head, wd 5e-3) on learnable labels, the HIP path in fp32 and bf16 mode vs the
-    oracle doing the same steps on the same batches; held-out pixel accuracy must agree within 1 % (absolute)."""
+    oracle doing the same steps on the same batches; held-out pixel accuracy must agree within 1 % (absolute).  Second case:
+    the size of the reference's shipped configs/finetune_config_enmap.yaml:1-32 with configs/config.yaml:19-24 (200 bands,
+    depth 4)."""
     from oracle import classify_forward
     from maskedsst_amd import ViTSpatialSpectral
-    cfg = dict(bands=80, depth=2, B=8, n_classes=8, spectral_pos_embed=False)
+    cfg = dict(bands=shape["bands"], depth=shape["depth"], B=shape["B"], n_classes=8, spectral_pos_embed=False)
     ocfg = oracle_cfg_from(cfg)
-    steps = 30
+    steps = shape["steps"]
     gen = torch.Generator().manual_seed(123)
     batches = [make_batch(gen, cfg["B"], cfg["bands"], cfg["n_classes"]) for _ in range(steps)]
     held, held_y = make_batch(gen, 64, cfg["bands"], cfg["n_classes"])
@@ -161,11 +238,11 @@ def test_config5_short_finetune_accuracy_vs_oracle():
         with torch.no_grad():
             acc = accuracy(enc(held.cuda()).cpu(), held_y)
         got[prec] = (acc, losses)
-    record("config5_finetune", ref_acc=ref_acc, acc_fp32=got["fp32"][0], acc_bf16=got["bf16"][0],
+    record("config5_finetune", shape=shape, ref_acc=ref_acc, acc_fp32=got["fp32"][0], acc_bf16=got["bf16"][0],
            ref_loss_last=ref_losses[-1], loss_fp32_last=got["fp32"][1][-1], loss_bf16_last=got["bf16"][1][-1])
     # the task is learnable but not saturated after 30 steps (oracle: loss 2.17 -> 0.78, held-out accuracy ~0.73 against
     # 0.125 chance), so a wrong gradient or update would move the accuracy
-    assert ref_losses[-1] < 0.5 * ref_losses[0] and 0.5 < ref_acc < 0.95, (ref_losses[0], ref_losses[-1], ref_acc)
+    assert ref_losses[-1] < 0.6 * ref_losses[0] and 0.4 < ref_acc < 0.97, (ref_losses[0], ref_losses[-1], ref_acc)
     np.testing.assert_allclose(got["fp32"][1], ref_losses, rtol=2e-3)
     assert abs(got["fp32"][0] - ref_acc) <= 0.01, (got["fp32"][0], ref_acc)
     assert abs(got["bf16"][0] - ref_acc) <= 0.01, (got["bf16"][0], ref_acc)

@@ -105,6 +105,51 @@ def test_dropout_bf16_depth12_same_masks():
     assert gerr[worst] < b["grad"], (worst, gerr[worst])
 
 
+def test_bf16_gradients_of_the_path_exactly_as_benchmarked():
+    """The one step no other test pins per tensor: HIP forward -> HIP sign(pred - target) -> HIP backward, end to end through
+    ``model(x).backward()`` exactly as bench.py runs it (bf16 kernels, training-mode dropout 0.1, depth 12).  The oracle gets the
+    kernels' own dropout masks AND the kernels' own L1 sign pattern (its backward runs on the surrogate loss
+    sum(pred * sign_hip) / (B K P) / K, whose gradient with respect to pred is what the L1 loss of reference
+    vit_simmim_original.py:338 hands back for that sign pattern), so every parameter-gradient tensor can be bounded in
+    relative L2 -- no flipped signs at pred ~= target in the way."""
+    from oracle import simmim_forward
+    cfg = dict(bands=50, depth=12, B=8)
+    p = 0.1
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    ocfg = oracle_cfg_from(cfg)
+    masks = model.draw_masks(cfg["B"])
+    model.encoder.dropout_p = p
+    model.train()
+    xc = x.cuda()
+    torch.manual_seed(777)
+    loss = model(xc, masks=masks)
+    loss.backward()
+    torch.cuda.synchronize()
+    got = {n: q.grad.detach().float().cpu().clone() for n, q in model.named_parameters() if q.grad is not None}
+    torch.manual_seed(777)
+    seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())   # what Engine.dropout_state drew for that forward
+    eng = model.engine()
+    out = eng.simmim_forward_stages(xc, masks[0], masks[1], drop=(p, seed))
+    torch.cuda.synchronize()
+    assert out["loss"].item() == loss.item()                 # same kernels, same masks: the staged forward IS that forward
+    sgn = out["dpred"].detach().float().cpu()
+    for q in params.values():
+        q.requires_grad_(True)
+    ref = simmim_forward(params, x, ocfg, masks=masks, drop_fn=make_drop_fn(p, seed, ocfg.S, ocfg.N, ocfg.heads))
+    B, K, P = ref["pred"].shape
+    flips = float((torch.sign(ref["pred"] - ref["target"]).detach() != sgn).float().mean())
+    ((ref["pred"] * sgn).sum() / (B * K * P) / K).backward()
+    gerr = {}
+    for name, g in got.items():
+        if params[name].grad is not None:
+            gerr[name] = rel_l2(g, params[name].grad)
+    worst = max(gerr, key=gerr.get)
+    record("bf16_grads_as_benchmarked", worst_grad=gerr[worst], worst_grad_name=worst, sign_flips=flips,
+           median_grad=float(np.median(list(gerr.values()))))
+    assert flips < 0.02, flips                                # the two sign patterns differ only where pred ~= target
+    assert gerr[worst] < BF16_DROP_BARS["grad"], (worst, gerr[worst])
+
+
 def test_dropout_training_mode_end_to_end_bf16():
     """model.train() with dropout=0.1: finite loss/grads, different masks per forward, eval() is deterministic"""
     from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral

@@ -327,6 +327,16 @@ def test_houston_spectral_positions_kat():
         assert got == g[f"pos_depth{depth}"].tolist(), depth
     assert get_spectral_pos_embedding("houston2018", 50, 10, g["houston_waves"], g["enmap_waves_valid"]) == [0, 3, 5, 7, 9]
     assert get_spectral_pos_embedding("dfc", 200, 10).tolist() == list(range(20))
+    with pytest.raises(NotImplementedError):   # as in the reference (src/utils.py:415-429): enmap is no finetune label set
+        get_spectral_pos_embedding("enmap", 200, 10)
+    # the shipped Houston2018 finetune config carries exactly this lookup result, and the entry point hands it to the model
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("finetune_entry_h", os.path.join(ROOT, "finetune.py"))
+    fin_mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fin_mod)
+    cfg = fin_mod.get_finetune_config(os.path.join(ROOT, "configs", "finetune_config_houston2018.yaml"),
+                                      os.path.join(ROOT, "configs", "config.yaml"), 5, "cpu")
+    assert cfg.spectral_pos.tolist() == [0, 3, 5, 7, 9] and cfg.n_bands == 50 and cfg.n_classes == 20
     with pytest.raises(NotImplementedError):
         get_spectral_pos_embedding("sentinel2", 12, 4)
 

@@ -45,11 +45,14 @@ def rel_l2(a, b):
 
 
 def record(test, **kv):
-    """Append a measured error to gpurun_out/parity_r02.jsonl (scratch; the round's copy lives in profiles/)."""
+    """With MSST_RECORD=1 (tools/final_prof.sh sets it), append a measured error to gpurun_out/parity_$MSST_ROUND.jsonl
+    (scratch; the round's copy lives in profiles/).  Ordinary test runs write nothing."""
+    if os.environ.get("MSST_RECORD") != "1":
+        return
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "parity_r02.jsonl"), "a") as f:
+        with open(os.path.join(d, "parity_%s.jsonl" % os.environ.get("MSST_ROUND", "dev")), "a") as f:
             f.write(json.dumps(dict(test=test, **kv)) + "\n")
     except OSError:
         pass

@@ -1,39 +1,53 @@
 # round-end evidence: rocprofv3 kernel stats of the default bench command, the default bench line, PMC passes
-# (HBM traffic; SQ/LDS counters), other configurations.  Everything lands in gpurun_out/final/;
-# `python tools/make_profiles.py rNN` then copies the judged summaries into profiles/.
-# usage (on the GPU box, through gpurun):  bash tools/final_prof.sh
+# (HBM traffic; SQ/LDS counters), other configurations, the box microbenchmark, the CU-contention sweep.
+# Everything lands in gpurun_out/final/; `python tools/make_profiles.py $TAG` then copies the judged summaries into profiles/.
+# usage (on the GPU box, through gpurun):  bash tools/final_prof.sh r03
+set -eu
+TAG="${1:?usage: final_prof.sh rNN}"
+cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 OUT=gpurun_out/final
-rm -rf $OUT; mkdir -p $OUT
-# parity measurements of the round (every bf16 bar in tests/ is <= 2x what this run records)
-rm -f gpurun_out/parity_r02.jsonl
-python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.txt; cat $OUT/gpu_tests.txt
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o r02 -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1
+rm -rf "$OUT"; mkdir -p "$OUT"
+export MSST_ROUND="$TAG" MSST_RECORD=1
+# parity measurements of the round (tests/util.py::record appends to gpurun_out/parity_$TAG.jsonl)
+rm -f "gpurun_out/parity_$TAG.jsonl"
+python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.txt || true; cat $OUT/gpu_tests.txt
+# box microbenchmark (MFMA / HBM / L2 / LDS access patterns)
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/peak_microbench.hip -o /tmp/peak_microbench && /tmp/peak_microbench > $OUT/peak_microbench.json
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1 || true
 find $OUT/stats -name "*kernel_trace.csv" -delete
-timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err
+timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err || true
 tail -1 $OUT/bench_default.json | cut -c1-600
-timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null
+timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline"
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
-  rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile > /dev/null 2>&1
+  rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- $B > /dev/null 2>&1 || true
 done
-B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -f csv -d $OUT/pmc_sq1 -- $B > /dev/null 2>&1
-rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_MFMA --kernel-trace -f csv -d $OUT/pmc_sq2 -- $B > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -f csv -d $OUT/pmc_sq1 -- $B > /dev/null 2>&1 || true
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS SQ_INSTS_MFMA --kernel-trace -f csv -d $OUT/pmc_sq2 -- $B > /dev/null 2>&1 || true
 python3 tools/pmc_summary.py $OUT/pmc_FETCH_SIZE > $OUT/pmc_fetch.txt
 python3 tools/pmc_summary.py $OUT/pmc_WRITE_SIZE > $OUT/pmc_write.txt
 ( python3 tools/pmc_summary.py $OUT/pmc_sq1; python3 tools/pmc_summary.py $OUT/pmc_sq2 ) > $OUT/pmc_sq.txt
-grep -A1 "block_" $OUT/pmc_fetch.txt; grep -A1 "block_" $OUT/pmc_write.txt
+grep -A1 "block_" $OUT/pmc_fetch.txt || true; grep -A1 "block_" $OUT/pmc_write.txt || true
 find $OUT -name "*.csv" -size +512k -delete
 # other configurations (parity-test shapes and the batch sweep), one line each
 ( python3 bench.py --no-cpu-baseline --dropout 0 | tail -1
   python3 bench.py --no-cpu-baseline --bands 50 | tail -1
   python3 bench.py --no-cpu-baseline --batch 64 | tail -1
   python3 bench.py --no-cpu-baseline --batch 1024 --steps 5 | tail -1
-  python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null
+  python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null || true
 cut -c1-200 $OUT/bench_other_configs.jsonl
+# CU contention: the step with N occupancy-probe workgroups held on a side stream, default grid and the DP grid
+( for n in 0 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done
+  for n in 0 8 16 32; do MSST_ATTN_CHUNKS=60 MSST_BWD_GRID=240 python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
+python3 - << 'PY'
+import json
+for l in open("gpurun_out/final/cu_contention.jsonl"):
+    d = json.loads(l); print(d.get("cu_thief"), d["ms_per_step"], d["value"])
+PY
 # data-parallel wiring on one GPU: a one-rank RCCL group, bucket hooks fired by the real backward (bench.py --force-dp)
-rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline > $OUT/dp_bench.txt 2>&1
-python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1; cat $OUT/dp_overlap.txt
+rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline > $OUT/dp_bench.txt 2>&1 || true
+python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1 || true; cat $OUT/dp_overlap.txt
 find $OUT/dp -name "*.csv" -size +512k -delete
-cp gpurun_out/parity_r02.jsonl $OUT/parity_measured.jsonl 2>/dev/null
-ls -la $OUT $OUT/stats/* | head -30
+cp "gpurun_out/parity_$TAG.jsonl" $OUT/parity_measured.jsonl 2>/dev/null || true
+ls -la $OUT | head -40

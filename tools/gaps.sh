@@ -1,4 +1,4 @@
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 rm -rf gpurun_out/gaps; mkdir -p gpurun_out/gaps
 rocprofv3 --kernel-trace --memory-copy-trace -f csv -d gpurun_out/gaps -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-profile > gpurun_out/gaps/out.txt 2>&1
 tail -1 gpurun_out/gaps/out.txt | cut -c1-200

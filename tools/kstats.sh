@@ -1,5 +1,5 @@
 # per-kernel rocprofv3 stats of a short default bench run: bash tools/kstats.sh [bench args]   (on the GPU box)
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 rm -rf gpurun_out/kstats; mkdir -p gpurun_out/kstats
 rocprofv3 --kernel-trace --stats -f csv -d gpurun_out/kstats -o ks -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipeline --no-profile "$@" > gpurun_out/kstats/out.txt 2>&1
 tail -1 gpurun_out/kstats/out.txt | cut -c1-160

@@ -4,7 +4,9 @@ import json, os, re, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "final")
 DST = os.path.join(ROOT, "profiles")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+if len(sys.argv) < 2:
+    raise SystemExit("usage: make_profiles.py rNN (the tag given to tools/final_prof.sh)")
+tag = sys.argv[1]
 
 def pmc(path, counter):
     out, name = {}, None
@@ -19,7 +21,7 @@ fetch = pmc(os.path.join(SRC, "pmc_fetch.txt"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write.txt"), "WRITE_SIZE")
 short = {"block_fwd_hw_kernel": "block_fwd", "block_bwd_attn": "block_bwd_attn", "block_bwd_ln1": "block_bwd_ln1",
          "block_bwd_mlp": "block_bwd_mlp", "tokenize_bwd": "tokenize_bwd", "tokenize_fwd": "tokenize_fwd",
-         "head_bwd": "head_bwd", "reduce_segs": "reduce_slabs"}
+         "head_bwd": "head_bwd", "reduce_segs": "reduce_slabs", "adamw_kernel": "adamw", "head_fwd": "head_fwd"}
 kern = {}
 for full, f in fetch.items():
     for pat, s in short.items():
@@ -30,16 +32,17 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
                      "--batch 256 (tools/final_prof.sh), final kernels of the round",
            "correction": "FETCH_SIZE x2 (gfx950 16B/lane streaming under-report, MI355X_MICROARCH.md), WRITE_SIZE x1; KB -> bytes",
            "kernels": kern}, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
-shutil.copy(os.path.join(SRC, "stats", "r02_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_bench_b256.csv"))
+shutil.copy(os.path.join(SRC, "stats", f"{tag}_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_bench_b256.csv"))
 shutil.copy(os.path.join(SRC, "bench_default.json"), os.path.join(DST, f"{tag}_bench_default.json"))
 shutil.copy(os.path.join(SRC, "bench_profile_all.json"), os.path.join(DST, f"{tag}_bench_b256_events.json"))
-shutil.copy(os.path.join(SRC, "bench_other_configs.jsonl"), os.path.join(DST, f"{tag}_bench_other_configs.json"))
+shutil.copy(os.path.join(SRC, "bench_other_configs.jsonl"), os.path.join(DST, f"{tag}_bench_other_configs.jsonl"))
 with open(os.path.join(DST, f"{tag}_pmc_summary.txt"), "w") as f:
     f.write("# rocprofv3 --pmc passes (SQ / LDS counters, then HBM FETCH_SIZE / WRITE_SIZE in KB) of bench.py --steps 1 --warmup 1\n")
     for n in ("pmc_sq.txt", "pmc_fetch.txt", "pmc_write.txt"):
         f.write(open(os.path.join(SRC, n)).read())
 for n, dst in (("dp_overlap.txt", f"{tag}_dp_overlap.txt"), ("parity_measured.jsonl", f"{tag}_parity_measured.jsonl"),
-               ("gpu_tests.txt", f"{tag}_gpu_tests.txt")):
+               ("gpu_tests.txt", f"{tag}_gpu_tests.txt"), ("peak_microbench.json", f"{tag}_peak_microbench.json"),
+               ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl")):
     if os.path.exists(os.path.join(SRC, n)):
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, dst))
 print(json.dumps(kern, indent=1))

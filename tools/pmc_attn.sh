@@ -1,6 +1,6 @@
 # SQ / LDS counters of the attention backward (and the forward) from one bench step: bash tools/pmc_attn.sh   (on the GPU box)
 set -u
-cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline"
 rm -rf gpurun_out/pmca; mkdir -p gpurun_out/pmca
 rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU --kernel-trace -f csv -d gpurun_out/pmca/a -- $B > /dev/null 2>&1

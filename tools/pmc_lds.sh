@@ -1,6 +1,6 @@
 # LDS counters of one kernel for build-flag variants: tools/pmc_lds.sh file.hip kernel_substr "<flags>" ...
 src=$1; kn=$2; shift; shift
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+set -eu; export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 for flags in "$@"; do
   touch maskedsst_amd/csrc/$src
   python3 - <<PY
