@@ -74,7 +74,11 @@ def main():
                     help="run N occupancy-probe workgroups (msst_debug_cu_thief: each holds one CU slot no MFMA workgroup fits beside) "
                          "on a side stream for the duration of every timed step -- what RCCL's channel workgroups take from the "
                          "backward under data parallelism, measured on one GPU")
-    ap.add_argument("--thief-us", type=float, default=25000.0, help="how long each probe launch holds its CUs (microseconds)")
+    ap.add_argument("--thief-us", type=float, default=17000.0,
+                    help="how long each probe launch holds its CUs (microseconds; the backward of the default step takes ~20 ms)")
+    ap.add_argument("--thief-reserve", type=int, default=-1,
+                    help="with --cu-thief: size the backward's persistent grids for this many CUs left free (Engine.reserve_cus, "
+                         "what attach_data_parallel does); -1 keeps the single-GPU grids")
     ap.add_argument("--force-dp", action="store_true",
                     help="single process, but through the data-parallel path: a one-rank RCCL process group, bucket hooks, "
                          "all-reduce calls, mean inside AdamW (MSST_FORCE_DP=1); for traces of the DP wiring on a 1-GPU box")
@@ -121,12 +125,22 @@ def main():
     g = torch.Generator(device="cpu").manual_seed(SEED + rank)
     img = torch.randn(B, args.bands, 8, 8, generator=g).to(dev)   # synthetic cubes, resident in HBM
 
+    thief = {"stream": None, "sink": None}
+
     def step():
         opt.zero_grad()
         loss = model(img)   # `img` is rebound by the pipeline-inclusive region below
+        if thief["stream"] is not None:
+            # occupancy probe under the BACKWARD (that is where RCCL's channel workgroups run): starts when the forward is done,
+            # holds its CUs for --thief-us; the optimizer step waits for it like it waits for the all-reduces
+            thief["stream"].wait_stream(torch.cuda.current_stream())
+            lib.msst_debug_cu_thief(args.cu_thief, int(args.thief_us), ctypes.c_void_p(thief["sink"].data_ptr()),
+                                    ctypes.c_void_p(thief["stream"].cuda_stream))
         loss.backward()
         if reducer is not None:
             opt.grad_scale = reducer.finish()
+        if thief["stream"] is not None:
+            torch.cuda.current_stream().wait_stream(thief["stream"])
         opt.step()
         return loss
 
@@ -162,19 +176,15 @@ def main():
     if prof:
         lib.msst_profile_enable(1)
     torch.cuda.synchronize()
-    thief_stream = torch.cuda.Stream() if args.cu_thief > 0 else None
-    thief_sink = torch.zeros(4, dtype=torch.int32, device=dev) if args.cu_thief > 0 else None
+    if args.cu_thief > 0:
+        thief["stream"], thief["sink"] = torch.cuda.Stream(), torch.zeros(4, dtype=torch.int32, device=dev)
+        if "MSST_ATTN_CHUNKS" not in os.environ and args.thief_reserve >= 0:
+            model.engine().reserve_cus(args.thief_reserve)   # the grids attach_data_parallel would select
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if thief_stream is not None:
-            # one probe launch per step, sized to outlast it; the next step's probe queues behind it on the side stream
-            thief_stream.wait_stream(torch.cuda.current_stream())
-            lib.msst_debug_cu_thief(args.cu_thief, int(args.thief_us), ctypes.c_void_p(thief_sink.data_ptr()),
-                                    ctypes.c_void_p(thief_stream.cuda_stream))
         loss = step()
-        if thief_stream is not None:
-            torch.cuda.current_stream().wait_stream(thief_stream)
     torch.cuda.synchronize()
+    thief["stream"] = None
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
@@ -239,7 +249,8 @@ def main():
         if args.force_dp:
             out["forced_dp"] = True
         if args.cu_thief:
-            out["cu_thief"] = {"workgroups": args.cu_thief, "hold_us": args.thief_us}
+            out["cu_thief"] = {"workgroups": args.cu_thief, "hold_us": args.thief_us, "reserved_cus": args.thief_reserve,
+                               "attn_chunks": model.engine().attn_chunks, "grid_rows": model.engine().grid_rows}
         if pipe is not None:
             out["pipeline_inclusive"] = pipe
         if kernels:

@@ -202,9 +202,11 @@ def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
     model.dp_world = dist.get_world_size(group) if dist.is_initialized() else 1
     red = BucketReducer(eng.fp.grad, eng.fp.buckets, group=group, bucket_bytes=bucket_bytes)
     eng.bucket_hook = red.bucket_ready
-    # RCCL's channel workgroups need CUs of their own while the backward runs: the persistent grids of the backward kernels are
-    # sized so that every workgroup is resident on the CUs left (a static 2-per-CU grid that loses CUs runs its displaced
-    # workgroups as a second wave behind the others; profiles/r03_dp_cu_contention.jsonl)
+    # RCCL's channel workgroups need CUs of their own while the backward runs.  The attention backward fills every CU slot
+    # with a statically partitioned persistent grid: a workgroup that finds no slot runs as a second wave BEHIND the others
+    # and doubles that launch.  Measured with bench.py --cu-thief (profiles/r03_dp_cu_contention.jsonl: 8-32 probe
+    # workgroups held under the whole backward): step +19 % on the single-GPU grids, still +19 % with 16 or 24 CUs left
+    # free, +3.5 % with 32 -- and the smaller grids cost nothing measurable when nothing contends.  Hence 32.
     if model.dp_world > 1 or os.environ.get("MSST_FORCE_DP", "0") == "1":
-        eng.reserve_cus(int(os.environ.get("MSST_DP_RESERVE_CUS", "16")))
+        eng.reserve_cus(int(os.environ.get("MSST_DP_RESERVE_CUS", "32")))
     return red

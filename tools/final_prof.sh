@@ -38,8 +38,9 @@ find $OUT -name "*.csv" -size +512k -delete
   python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null || true
 cut -c1-200 $OUT/bench_other_configs.jsonl
 # CU contention: the step with N occupancy-probe workgroups held on a side stream, default grid and the DP grid
-( for n in 0 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done
-  for n in 0 8 16 32; do MSST_ATTN_CHUNKS=60 MSST_BWD_GRID=240 python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
+( python3 bench.py --no-cpu-baseline --no-pipeline --no-profile | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done
+  for r in 16 32; do for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --thief-reserve $r | tail -1; done; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
 python3 - << 'PY'
 import json
 for l in open("gpurun_out/final/cu_contention.jsonl"):
