@@ -23,6 +23,7 @@
 #include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
+#include <type_traits>
 
 #ifndef MSST_B3_D3A
 #define MSST_B3_D3A 2   // software-pipeline depths (steps a fragment is requested ahead of its MFMAs): phase 3 contraction,
@@ -110,6 +111,9 @@ __device__ __forceinline__ s16x8 ld_w32(const void* w, int f, int lane16) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x7fffffff, 0x00020000);
     return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, f * 1024, 0));
 }
+__device__ __forceinline__ void bar3() {
+    if (MSST_B3_EXP & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else lds_barrier();
+}
 __device__ __forceinline__ int launder3(int v) {
     asm volatile("" : "+v"(v));
     return v;
@@ -156,6 +160,16 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
         rowmap[tid] = ((unsigned)((sq >= tm.TS ? 0xffff : sq) & 0xffff) << 16) | (unsigned)ps;
     }
     __syncthreads();
+    // key tiles (16 keys each) that the 16 queries of this wave can see: those overlapping [first key of the first query's
+    // sequence, last key of the last query's sequence]
+    unsigned need;
+    {
+        const int r0 = 16 * wave, r1 = 16 * wave + 15;
+        const int klo = r0 - (int)(rowmap[r0] & 0xffffu), khi = min(63, r1 - (int)(rowmap[r1] & 0xffffu) + L - 1);
+        unsigned m = 0;
+        for (int t = 0; t < 4; ++t) m |= (unsigned)(16 * t <= khi && 16 * t + 15 >= klo) << t;
+        need = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    }
     // token of tile row `sp` (a rowmap entry) in tile tile_, -1 for padding
     auto tok_sp = [&](int tile_, unsigned sp) -> int {
         const int sx = (int)(sp >> 16), sy = (int)(sp & 0xffffu);
@@ -264,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
         }
         STAMP(2);
-        lds_barrier();   // B1
+        bar3();   // B1
         STAMP(3);
         B3_PRIO(0);
         R3_DUMP(1);
@@ -282,70 +296,76 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 aq[ks2] = ak[ks2] + wave * 2048;
             }
             const unsigned L8 = (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);   // ^ (t << 5)
-            f32x4 pr[4];
-            {
-                s16x8 fq[2], fk[2][4];
-#pragma unroll
-                for (int ks2 = 0; ks2 < 2; ++ks2) {
-                    fq[ks2] = lds_r128(sm, R3_Q + aq[ks2]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) fk[ks2][t] = lds_r128(sm, R3_K + ak[ks2] + t * 2048);
-                }
-#pragma unroll
-                for (int t = 0; t < 4; ++t) pr[t] = zero4();
-#pragma unroll
-                for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) pr[t] = P::mma(fk[ks2][t], fq[ks2], pr[t]);   // C[i = key][j = query]
-            }
-            // operands of dP^T = v dO^T requested under the softmax
-            s16x8 fdo[2], fv[2][4];
-#pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2) {
-                fdo[ks2] = lds_r128(sm, R3_DO + aq[ks2]);
-#pragma unroll
-                for (int t = 0; t < 4; ++t) fv[ks2][t] = lds_r128(sm, R3_V + ak[ks2] + t * 2048);
-            }
-            // dP^T = v dO^T is independent of the softmax: its MFMAs run under the softmax's VALU work
-            f32x4 dp[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) dp[t] = zero4();
-#pragma unroll
-            for (int ks2 = 0; ks2 < 2; ++ks2)
-#pragma unroll
-                for (int t = 0; t < 4; ++t) dp[t] = P::mma(fv[ks2][t], fdo[ks2], dp[t]);   // C[i = key][j = query]
+            // Short sequences (spectral blocks): a wave's 16 queries only meet the key tiles that overlap their own sequences -- bit t
+            // of `need` (wave uniform, tile invariant).  Every other 16 x 16 score tile is masked anyway and is skipped altogether
+            // (operand reads, MFMAs, exps, dropout hashes); its P / dS entries are stored as zeros.
+            f32x4 pr[4], dp[4];
             f32x4 dm[4];   // dropout multipliers of site 1 (0 or 1 / (1 - p)): P and dP see the same ones
-            {
-                // same arithmetic as block_fwd_hw_kernel: exp2(s c - max c), c = scale log2 e; nothing to mask when L == 64
-                const float cs = a.scale * 1.44269504088896340736f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dm[t] = zero4();
+            const float cs = a.scale * 1.44269504088896340736f;   // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e
+            auto softmax_phase = [&](auto masked_tag) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                const unsigned nm = MASKED ? need : 0xfu;
+                auto on = [&](int t) { return !MASKED || ((nm >> t) & 1u); };
+                {
+                    s16x8 fq[2], fk[2][4];
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ++ks2) {
+                        fq[ks2] = lds_r128(sm, R3_Q + aq[ks2]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) fk[ks2][t] = lds_r128(sm, R3_K + ak[ks2] + t * 2048);   // (all of them: a definition on every path)
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) pr[t] = zero4();
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (on(t)) pr[t] = P::mma(fk[ks2][t], fq[ks2], pr[t]);   // C[i = key][j = query]
+                }
+                // dP^T = v dO^T is independent of the softmax: its operands are requested and its MFMAs run under the softmax's VALU work
+                {
+                    s16x8 fdo[2], fv[2][4];
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ++ks2) {
+                        fdo[ks2] = lds_r128(sm, R3_DO + aq[ks2]);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) fv[ks2][t] = lds_r128(sm, R3_V + ak[ks2] + t * 2048);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) dp[t] = zero4();
+#pragma unroll
+                    for (int ks2 = 0; ks2 < 2; ++ks2)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (on(t)) dp[t] = P::mma(fv[ks2][t], fdo[ks2], dp[t]);   // C[i = key][j = query]
+                }
                 float mx = -INFINITY;
-                if (L == 64) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) continue;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, pr[t][r]);
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
+                    for (int r = 0; r < 4; ++r) {
+                        if (MASKED) {
                             const int key = t * 16 + 4 * g + r;
-                            const float v = (key >= qlo && key < qhi) ? pr[t][r] : -INFINITY;
-                            pr[t][r] = v;
-                            mx = fmaxf(mx, v);
+                            pr[t][r] = (key >= qlo && key < qhi) ? pr[t][r] : -INFINITY;
                         }
+                        mx = fmaxf(mx, pr[t][r]);
+                    }
                 }
                 mx = colgroup_max(mx);
                 const float mc = mx * cs;
                 float sum = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) continue;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(pr[t][r], cs, -mc)); pr[t][r] = e; sum += e; }
+                }
                 sum = colgroup_sum(sum);
                 const float inv = 1.f / sum;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) { lds_w64(sm, R3_P + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
                     pr[t] = pr[t] * inv;
                     f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                     if (DROP) {
@@ -360,27 +380,29 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
                 }
-            }
-            {
-                if (DROP) {
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) dp[t] = dp[t] * dm[t];
-                }
                 float delta = 0.f;
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) continue;
+                    if (DROP) dp[t] = dp[t] * dm[t];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) delta += pr[t][r] * dp[t][r];
+                }
                 delta = colgroup_sum(delta);
                 // dS WITHOUT the softmax scale (dim_head^-0.5 = 2^-3, exact in bf16): it is folded into the q / k blocks of the
                 // phase-4 weights (msst_prep_weights, pack = 2) and into the dWq / dWk slabs at the end of the kernel
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) { lds_w64(sm, R3_DS + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
                     f32x4 d4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta);
                     lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
+            };
+            if (!(MSST_B3_EXP & 16)) {
+                if (L == 64) softmax_phase(std::false_type{});
+                else softmax_phase(std::true_type{});
             }
         }
         STAMP(4);
@@ -426,7 +448,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             };
 #pragma unroll
             for (int kk = 0; kk < D3; ++kk) issue_b(kk);
-            lds_barrier();   // B2
+            bar3();   // B2
             STAMP(5);
             B3_PRIO(1);
             R3_DUMP(2);
@@ -484,9 +506,9 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             for (int k12 = 0; k12 < 6; ++k12)
                 w4[k12] = ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
             tokn = load_rows(tile + gridDim.x, xnq, daq);
-            wgrad();
+            if (!(MSST_B3_EXP & 64)) wgrad();
             STAMP(6);
-            lds_barrier();   // B3
+            bar3();   // B3
             STAMP(7);
             R3_DUMP(3);
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
@@ -496,7 +518,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
                 c4[0] = zero16(); c4[1] = zero16();
                 s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
-                swpipe<12, MSST_B3_D4>(
+                if (!(MSST_B3_EXP & 32)) swpipe<12, MSST_B3_D4>(
                     [&](int k12) {
                         const int which = k12 >> 2, ks = k12 & 3;
                         const int reg = which == 0 ? R3_K : which == 1 ? R3_Q : R3_DO;
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             store_rows(tokn, xnq, daq);
         }
         STAMP(8);
-        lds_barrier();   // B4
+        bar3();   // B4
         STAMP(9);
         B3_PRIO(0);
         R3_DUMP(4);

@@ -124,7 +124,8 @@ def main():
         model, params, x = build_product(cfg, precision="bf16", device="cuda")
         eng = model.engine()
         masks = model.draw_masks(cfg["B"])
-        out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=(0.1, 5))
+        tdrop = (0.0, 0) if "nodrop" in sys.argv else (0.1, 5)
+        out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=tdrop)
         dy = torch.randn_like(out["enc_out"]) * 1e-3
         res = {0: [], 32: []}
         for rnd in range(4):
@@ -132,7 +133,7 @@ def main():
                 os.environ["MSST_DBG"] = str(flag)
                 eng.lib.msst_profile_enable(1)
                 for _ in range(8):
-                    eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=(0.1, 5))
+                    eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=tdrop)
                 torch.cuda.synchronize()
                 n = eng.lib.msst_profile_kernels()
                 tot = (ctypes.c_double * n)()
