@@ -322,6 +322,7 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
     }
     // 2. attention half, per (chunk, head)
+    int nparts = heads;
     {
         aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
         aa.xn = fast_rows ? xn_saved : nullptr; aa.dab = fast_rows ? dab_ws : nullptr;
@@ -332,13 +333,13 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
         aa.stamps = g_stamps;
         if (g_stamps) aa.dbg = dbg;
 #endif
-        int rc = launch_block_bwd_attn(aa, nc, prec, st);
+        int rc = launch_block_bwd_attn(aa, nc, prec, st, &nparts);
         if (rc) return fail(rc, "msst_block_bwd(attn)");
     }
     // 3. LN1 backward + residual
     {
         Ln1BwdArgs a;
-        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = heads; a.drop = drop;
+        a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = nparts; a.drop = drop;
         int rc = launch_block_bwd_ln1(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(ln1)");
     }

@@ -1417,9 +1417,10 @@ int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st
     return (int)hipGetLastError();
 }
 
-int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st) {
+int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st, int* nparts) {
     static std::atomic<bool> d0{false}, d1{false};
     if (a.tm.L > 64 || a.tm.L < 1) return MSST_ERR_UNSUPPORTED;
+    *nparts = a.H;   // d(LN1 out) partials written: one per head, or one per head pair (two-head kernel)
     dim3 grid(nchunk, a.H);
     if (prec == MSST_PREC_F32) {
         const size_t smem = sizeof(AttnBwdSmem<PF32>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad
@@ -1429,7 +1430,11 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
     } else if (!(a.dbg & 16)) {
         // MSST_DBG=16 selects the template kernel below (reference for the tuned ones), 32 the round-2 tuned kernel
-        if (!(a.dbg & 32) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) return launch_block_bwd_attn_r3(a, nchunk, st);
+        // 64 the one-head-per-workgroup round-3 kernel; default: two heads per workgroup (msst_bwd4.hip)
+        if (!(a.dbg & 32) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) {
+            if (!(a.dbg & 64) && !(a.H & 1)) { *nparts = a.H / 2; return launch_block_bwd_attn_r4(a, nchunk, st); }
+            return launch_block_bwd_attn_r3(a, nchunk, st);
+        }
         return launch_block_bwd_attn_bf16(a, nchunk, st);
     } else {
         const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad

@@ -119,10 +119,11 @@ def test_param_grads_bf16(cfg):
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
 @pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-@pytest.mark.parametrize("tuned", [0, 32], ids=["r3", "r2"])
+@pytest.mark.parametrize("tuned", [0, 64, 32], ids=["r4", "r3", "r2"])
 def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
-    """The tuned bf16 attention backward kernels -- round 3 (msst_bwd3.hip: one GEMM per wave, 32x32x16 MFMAs, swizzled LDS
-    tiles; the default) and round 2 (msst_bwd2.hip, MSST_DBG=32), both fed with the LN1 rows saved by the forward and the
+    """The tuned bf16 attention backward kernels -- round 3, two heads per workgroup (msst_bwd4.hip; the default), round 3, one
+    head per workgroup (msst_bwd3.hip: one GEMM per wave, 32x32x16 MFMAs, swizzled LDS tiles; MSST_DBG=64, and the fallback for
+    an odd head count) and round 2 (msst_bwd2.hip, MSST_DBG=32), all fed with the LN1 rows saved by the forward and the
     pre-dropped bf16 da rows left by the MLP half -- against the template kernel (msst_bwd.hip, MSST_DBG=16; re-reads
     x / dx1, renormalises, applies the to_out dropout itself): same bf16 operands and the same dropout masks up to summation
     order, so every gradient tensor must agree far inside the bf16-vs-oracle tolerance (spatial and spectral tiles, 64- and
@@ -144,7 +145,11 @@ def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
     dx_old, g_old = run()
     monkeypatch.delenv("MSST_DBG")
     e_dx = rel_l2(dx_new, dx_old)
-    assert e_dx < 5e-4, e_dx   # measured 1.6e-4 (dx), 1.6e-3 (worst gradient tensor)
+    # r3 / r2 round where the template rounds (measured 1.6e-4 dx, 1.6e-3 worst gradient tensor); r4 rounds the d(LN1 out)
+    # partial of a head PAIR to bf16 (A's rows, then the sum) where the others round one partial per head: a bf16-level
+    # difference (measured 7.6e-4 dx, 3.1e-3 worst gradient tensor), invisible against the oracle (test_param_grads_bf16)
+    bar_dx, bar_g = (1.5e-3, 6.3e-3) if tuned == 0 else (5e-4, 3.2e-3)
+    assert e_dx < bar_dx, e_dx
     bad, worst = [], 0.0
     for name, p in eng.trainable():
         a, b = eng.fp.view(name, g_new), eng.fp.view(name, g_old)
@@ -152,7 +157,7 @@ def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
             continue
         e = rel_l2(a, b)
         worst = max(worst, e)
-        if not e < 3.2e-3:
+        if not e < bar_g:
             bad.append((name, e))
-    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), kernel="r2" if tuned else "r3", dx=e_dx, worst_grad=worst)
+    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), kernel={0: "r4", 64: "r3", 32: "r2"}[tuned], dx=e_dx, worst_grad=worst)
     assert not bad, bad
