@@ -1072,7 +1072,14 @@ __global__ __launch_bounds__(256) void block_bwd_ln1_kernel(Ln1BwdArgs a) {
 #pragma unroll
     for (int i = 0; i < FPT; ++i) { dg[i] = 0.f; db[i] = 0.f; dbo[i] = 0.f; gam[i] = a.ln1_g[part * FPT + i]; }
     const int ntiles = (a.ntok + ROWS - 1) / ROWS;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#ifndef MSST_LN1_REV
+#define MSST_LN1_REV 1
+#endif
+    // the walk runs from the last tile to the first: the attention kernel before this one wrote its partials (and the MLP
+    // kernel dx1) in ascending tile order, so the rows most likely to be still in the memory-side cache are read first
+    const int tile_last = (int)blockIdx.x + ((ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
+    for (int tile_ = blockIdx.x; tile_ < ntiles; tile_ += gridDim.x) {
+        const int tile = MSST_LN1_REV ? tile_last - (tile_ - (int)blockIdx.x) : tile_;
         const long tok = (long)tile * ROWS + r;
         if (tok < a.ntok) {   // the threads of a row are in/out together
             float v[FPT], dn[FPT];

@@ -29,10 +29,10 @@
 #define MSST_B3_D4 3    // phase 4
 #endif
 #ifndef MSST_B3_W4
-#define MSST_B3_W4 6    // phase-4 weight fragments requested before the weight-gradient GEMM (the other 12 - n during phase 4)
+#define MSST_B3_W4 6    // phase-4 weight fragments in registers (a ring: n requested before barrier B3, the other 12 - n as phase 4 frees slots)
 #endif
 #ifndef MSST_B3_W1AT
-#define MSST_B3_W1AT 6   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
+#define MSST_B3_W1AT 8   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
 #endif
 #ifndef MSST_B3_EXP
 #define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = no row requests
@@ -66,7 +66,7 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr int R4_ROWBUF = 24576, R4_DA = 12288;
 constexpr int R4_G0 = 49152, R4_GSZ = 49152;
 constexpr int R3_Q = 0, R3_K = 8192, R3_DO = 16384, R3_V = 24576, R3_P = 32768, R3_DS = 40960;
-constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SMEM = 160000;
+constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SEQ = 160000, R4_SEQO = 160272, R4_SMEM = 160272 + 272;   // row map [64], sequence bases [65] x 2
 
 // 16-byte slot s of row r lives at slot s ^ fz(r) (128-byte rows) / (s & ~3) | ((s & 3) ^ fz2(r)) (192-byte rows)
 __device__ __forceinline__ int fz(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 3) & 1); }
@@ -110,6 +110,13 @@ __device__ __forceinline__ s16x8 pk8(const f32x16& c, int k0) {
 __device__ __forceinline__ s16x8 ld_w32(const void* w, int f, int lane16) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x7fffffff, 0x00020000);
     return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, f * 1024, 0));
+}
+// 16 bytes per lane, global -> LDS without passing registers: lane i's bytes land at lds_dst + 16 i (lds_dst wave uniform, below
+// 64 KB); a lane whose offset lies outside the descriptor writes zeros.  Opaque to the compiler's vmcnt bookkeeping (the builtin
+// form makes every later LDS read wait for vmcnt(0)): loads return in order, so the compiler's own waits only become more
+// conservative, and the consumer side is ordered by an explicit vmcnt(0) + barrier.
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_dst, unsigned voff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs) : "memory", "m0");
 }
 __device__ __forceinline__ void bar3() {
     if (MSST_B3_EXP & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else lds_barrier();
@@ -172,72 +179,88 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         for (int t = 0; t < 4; ++t) m |= (unsigned)(16 * t <= khi && 16 * t + 15 >= klo) << t;
         need = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     }
-    // token of tile row `sp` (a rowmap entry) in tile tile_, -1 for padding
-    auto tok_sp = [&](int tile_, unsigned sp) -> int {
-        const int sx = (int)(sp >> 16), sy = (int)(sp & 0xffffu);
-        const int q = tile_ * tm.TS + sx;
-        if (tile_ >= a.ntiles || sx == 0xffff || q >= tm.nseq) return -1;
-        if (tm.mode == 0) return q * tm.N + sy;
-        const int b = tm.nshift >= 0 ? (q >> tm.nshift) : q / tm.N;
-        return b * tm.T + sy * tm.N + (q - b * tm.N);
-    };
     // row-wise LDS address of this thread's j-th 16-byte slot (row tid / 4, logical slot 3 (tid % 4) + j) in a 96-wide tile
     auto row_slot = [&](int j) -> unsigned {
         const int t_ = launder3(tid);
         const int row = t_ >> 2, s = 3 * (t_ & 3) + j;
         return (unsigned)(row * 192 + (((s & ~3) | ((s & 3) ^ fz2(row))) << 4));
     };
-    // The LN1(x) / da rows of the NEXT tile are staged through registers by head A's waves: thread <-> (row tid / 4, 48 bytes),
-    // three 16-byte loads of each array, requested at the start of the weight-gradient GEMM (an HBM round trip under load is
-    // 2-3 k cycles) and stored into the other row buffer before barrier B4 (its last reader, head B's weight-gradient GEMM
-    // of the tile before, finished three barriers earlier).  Padding rows: clamped address, zeros stored.  Head B's waves
-    // request token 0 (one hot line) and store nothing: a definition on every path keeps the register allocation of the
-    // two heads identical.
-    auto load_rows = [&](int tile_, u32x4 (&xr)[3], u32x4 (&dr)[3]) -> int {
-        const int t_ = launder3(tid);
-        const int tok = ((MSST_B3_EXP & 4) || grp) ? 0 : tok_sp(tile_, rowmap[t_ >> 2]);
-        const long off = (long)(tok >= 0 ? tok : 0) * 96 + (t_ & 3) * 24;
-        const u32x4* sx = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(a.xn) + off);
-        const u32x4* sd = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(a.dab) + off);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { xr[j] = sx[j]; dr[j] = sd[j]; }
-        return tok;
+    // The LN1(x) / da rows of the NEXT tile go straight from HBM into the other row buffer (LDS-DMA, head A's waves: 1 KB per
+    // instruction, three instructions per wave and array): lane <-> 16-byte LDS position p of the 12 KB array, which holds
+    // logical slot s of row p / 12 (the swizzle is an involution), fetched from token(row) * 192 + 16 s; a padding row's
+    // offset lies outside the descriptor and is zero filled.  Requested right behind barrier B2 -- the buffer's last reader,
+    // head B's weight-gradient GEMM of the tile before, finished one barrier earlier -- and waited for before barrier B4.
+    const __amdgpu_buffer_rsrc_t rows_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.xn), 0, (int)(a.ntok * 192), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rows_d = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dab), 0, (int)(a.ntok * 192), 0x00020000);
+    // token arithmetic stays off the issuing waves' critical path: wave O of head A leaves the token of position 0 of every
+    // sequence slot of the tile being fetched in a 64-entry LDS table (one integer division per lane and tile, during the softmax
+    // phase), and what a lane needs besides -- slot of the table, byte offset of its 16 bytes from that token -- is tile invariant
+    int* const seqbase = reinterpret_cast<int*>(smem_raw + R4_SEQ);   // [64] = -1: padding rows
+    int* const seqout = reinterpret_cast<int*>(smem_raw + R4_SEQO);   // the same for the copy-out: sequence bases of head B's current tile
+    auto fill_seqbase = [&](int* table, int tile_) {
+        const int sx = launder3(tid) & 63;
+        const int q = tile_ * tm.TS + sx;
+        int base = -1;
+        if (tile_ < a.ntiles && sx < tm.TS && q < tm.nseq) {
+            if (tm.mode == 0) base = q * tm.N;
+            else { const int b = tm.nshift >= 0 ? (q >> tm.nshift) : q / tm.N; base = b * tm.T + (q - b * tm.N); }
+        }
+        table[sx] = base;
     };
-    auto store_rows = [&](int buf, int tok, const u32x4 (&xr)[3], const u32x4 (&dr)[3]) {
+    if (wv == 3) { fill_seqbase(seqbase, blockIdx.x); if ((tid & 63) == 0) { seqbase[64] = -1; seqout[64] = -1; } }
+    __syncthreads();
+    unsigned rinv[3], rsx[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const unsigned o = buf + row_slot(j);
-            *reinterpret_cast<lds_u32x4*>(sm + o) = tok >= 0 ? xr[j] : u32x4{0u, 0u, 0u, 0u};
-            *reinterpret_cast<lds_u32x4*>(sm + R4_DA + o) = tok >= 0 ? dr[j] : u32x4{0u, 0u, 0u, 0u};
+    for (int jj = 0; jj < 3; ++jj) {
+        const int p = 192 * wave + 64 * jj + (tid & 63);
+        const int row = p / 12, sl = p - 12 * row;
+        const int s_ = (sl & ~3) | ((sl & 3) ^ fz2(row));
+        const unsigned sp = rowmap[row];
+        rsx[jj] = (unsigned)(R4_SEQ + 4 * min((int)(sp >> 16), 64));
+        rinv[jj] = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)s_ * 16u;
+    }
+    auto dma_rows = [&](int buf) {
+        int base[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) base[jj] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sm + rsx[jj]);
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {
+            const int bs = (MSST_B3_EXP & 4) ? 0 : base[jj];
+            const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + rinv[jj];
+            const unsigned dst = (unsigned)(buf + 3072 * wave + 1024 * jj);
+            dma16(rows_x, dst, voff);
+            dma16(rows_d, dst + R4_DA, voff);
         }
     };
-    if (!grp) {
-        u32x4 xr[3], dr[3];
-        const int tok0 = load_rows(blockIdx.x, xr, dr);
-        store_rows(0, tok0, xr, dr);
-    }
+    if (!grp) { dma_rows(0); wait_vm0(); }
     // copy-out of a finished tile (head B's waves; both heads' rows were summed in OUT by B's phase 4, published by barrier B4):
     // whole rows to the head pair's partial; buffer stores, a padding row gets an offset outside the descriptor and is dropped.
-    auto copy_out = [&](int tile_) {
-        const int t_ = launder3(tid);
-        const int tok_out = tok_sp(tile_, rowmap[t_ >> 2]);
+    unsigned cinv, csx;   // copy-out: thread <-> (row tid / 4, 48 bytes)
+    {
+        const unsigned sp = rowmap[tid >> 2];
+        csx = (unsigned)(R4_SEQO + 4 * min((int)(sp >> 16), 64));
+        cinv = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)(tid & 3) * 48u;
+    }
+    auto copy_out = [&]() {
+        const int bs = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sm + csx);
         u32x4 v[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const lds_u32x4*>(sm + R4_OUT + row_slot(j));
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(a.ntok * 192), 0x00020000);
-        const unsigned voff = tok_out < 0 ? 0x80000000u : (unsigned)tok_out * 192u + (t_ & 3) * 48;   // (+ 32 must not wrap)
+        const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + cinv;   // (+ 32 must not wrap)
 #pragma unroll
         for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 16 * j, 0, 0);
     };
-    const int last_tile = (int)blockIdx.x + ((a.ntiles - 1 - (int)blockIdx.x) / (int)gridDim.x) * (int)gridDim.x;
-    s16x8 w1[2][4];   // phase-1 weight fragments [d tile][k step % 4]: a ring of four k-steps (tile invariant, re-requested from L2 every tile)
-#define W1_(dt, s4) w1[(dt)][(s4)]
+    // phase-1 weight fragments [d tile][k step]: tile invariant, but 48 registers the softmax phase has no room for -- all twelve
+    // are re-requested from L2 during phase 4 of the tile before (the rows no longer pass registers: a ring of eight refilled
+    // inside phase 1 left its last two k-steps waiting on L2)
+    s16x8 w1[2][6];
     auto load_w1 = [&]() {
         const int l16 = (launder3(tid) & 63) * 16;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) W1_(dt, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
+            for (int ks = 0; ks < 6; ++ks) w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
     };
     load_w1();
     lds_barrier();   // the first tile's rows are in row buffer 0
@@ -278,14 +301,10 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     fb[ks % 3][1] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + 32 * 192);
                 },
                 [&](int ks) {
-                    c[0][0] = mma32(W1_(0, ks & 3), fb[ks % 3][0], c[0][0]);
-                    c[0][1] = mma32(W1_(0, ks & 3), fb[ks % 3][1], c[0][1]);
-                    c[1][0] = mma32(W1_(1, ks & 3), fb[ks % 3][0], c[1][0]);
-                    c[1][1] = mma32(W1_(1, ks & 3), fb[ks % 3][1], c[1][1]);
-                    if (ks < 2) {
-                        W1_(0, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + ks + 4, (t_ & 63) * 16);
-                        W1_(1, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 + ks + 4, (t_ & 63) * 16);
-                    }
+                    c[0][0] = mma32(w1[0][ks], fb[ks % 3][0], c[0][0]);
+                    c[0][1] = mma32(w1[0][ks], fb[ks % 3][1], c[0][1]);
+                    c[1][0] = mma32(w1[1][ks], fb[ks % 3][0], c[1][0]);
+                    c[1][1] = mma32(w1[1][ks], fb[ks % 3][1], c[1][1]);
                 });
             const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
 #pragma unroll
@@ -297,11 +316,13 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (grp && tile != (int)blockIdx.x) copy_out(tile - (int)gridDim.x);
+        if (grp && tile != (int)blockIdx.x) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
         B4_PRIO(2);
+        if (wv == 3) fill_seqbase(seqbase, tile + (int)gridDim.x);   // (read by head A's row requests behind barrier B2)
+        if (wv == 7) fill_seqbase(seqout, tile);                        // (read by head B's copy-out of this tile, three barriers on)
         // ---------------- phase 2: wave <-> 16 query rows; S^T, softmax, P, dP^T, dS (16 x 16 x 32 MFMAs) ----------------
         {
             typedef PBF16 P;
@@ -444,9 +465,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         // The second operand (k | q | dO | v) has been complete since barrier B1: its first fragments are requested BEFORE
         // barrier B2, so the phase starts with its MFMAs instead of an LDS round trip.
         {
-            s16x8 w4[6];            // phase-4 weight fragments of this wave's m tile: a ring of six, refilled as phase 4 consumes them
-            u32x4 xnq[3], daq[3];   // rows of the next tile
-            int tokn;
+            s16x8 w4[MSST_B3_W4];   // phase-4 weight fragments of this wave's m tile: a ring, refilled as phase 4 consumes them
             const int t_ = launder3(tid);
             const int l = t_ & 63, l31 = l & 31, hi = l >> 5, i = l & 15, u = (l >> 4) & 1, b = (i >> 1) & 1, r1 = (i >> 3) & 1;
             // transposed 32-column fragment of a 64-wide tile, natural contraction order: k row = 16 kk + 8 hi + 4 a + i / 4
@@ -482,6 +501,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             R4_STAMP(3);
             bar3();   // B2
             R4_STAMP(4);
+            if (!grp) dma_rows(R4_ROWBUF - xb);
             B4_PRIO(3);
 #pragma unroll
             for (int kk = 0; kk < D3; ++kk) issue_a(kk);
@@ -534,9 +554,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // (wave O, which has no phase 4, requests one hot fragment six times: a definition on every path keeps the register
             // allocator from shuffling the in-flight fragments of the other waves at the join)
 #pragma unroll
-            for (int k12 = 0; k12 < 6; ++k12)
+            for (int k12 = 0; k12 < MSST_B3_W4; ++k12)
                 w4[k12] = ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
-            tokn = load_rows(tile + gridDim.x, xnq, daq);
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
@@ -559,10 +578,10 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         fb4[k12 % (MSST_B3_D4 + 1)][1] = lds_tr2(sm, reg + tr[1][0] + 2048 * ks, reg + tr[1][1] + 2048 * ks);
                     },
                     [&](int k12) {
-                        c4[0] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][0], c4[0]);
-                        c4[1] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][1], c4[1]);
-                        if (k12 < 6)
-                            w4[k12] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + 6) >> 2) * (inner >> 4) + ((k12 + 6) & 3), l16);
+                        c4[0] = mma32(w4[k12 % MSST_B3_W4], fb4[k12 % (MSST_B3_D4 + 1)][0], c4[0]);
+                        c4[1] = mma32(w4[k12 % MSST_B3_W4], fb4[k12 % (MSST_B3_D4 + 1)][1], c4[1]);
+                        if (k12 + MSST_B3_W4 < 12)
+                            w4[k12 % MSST_B3_W4] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + MSST_B3_W4) >> 2) * (inner >> 4) + ((k12 + MSST_B3_W4) & 3), l16);
                         if (k12 == MSST_B3_W1AT) load_w1();   // the next tile's phase-1 weights, behind this phase's last weight request
                     });
                 // head A stages its rows; head B, two phases later, adds its own onto them (fp32 add of the bf16 values, one rounding)
@@ -581,7 +600,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, o, f2bf4(t4));
                     }
             }
-            if (!grp) store_rows(R4_ROWBUF - xb, tokn, xnq, daq);
+            if (!grp) wait_vm0();   // the next tile's rows are in LDS
         }
         R4_STAMP(7);
         bar3();   // B4
@@ -591,7 +610,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
         for (int i = 0; i < MSST_B4_LAG; ++i) lds_barrier();   // head A: the barriers head B is behind
     } else {
-        copy_out(last_tile);
+        copy_out();
     }
 
     // ---------------- slab: [dWq | dWk | dWv] [3][64][96], dWout_h [96][64] ----------------
