@@ -304,17 +304,21 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #pragma unroll
             for (int t = 0; t < 4; ++t) dm[t] = zero4();
             const float cs = a.scale * 1.44269504088896340736f;   // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e
-            auto softmax_phase = [&](auto masked_tag) {
-                constexpr bool MASKED = decltype(masked_tag)::value;
-                const unsigned nm = MASKED ? need : 0xfu;
-                auto on = [&](int t) { return !MASKED || ((nm >> t) & 1u); };
+            // NM: -1 = one 64-token sequence, nothing masked; > 0 = short sequences, the key tiles of this wave known at compile
+            // time (straight-line code: the run-time form below breaks the phase into thirty basic blocks and costs 1.5 k cycles);
+            // 0 = short sequences, key tiles from `need` at run time (patterns without an instance)
+            auto softmax_phase = [&](auto mode_tag) {
+                constexpr int NM = decltype(mode_tag)::value;
+                constexpr bool MASKED = NM >= 0;
+                const unsigned nm = NM > 0 ? (unsigned)NM : NM == 0 ? need : 0xfu;
+                auto on = [&](int t) { return NM < 0 || ((nm >> t) & 1u); };
                 {
                     s16x8 fq[2], fk[2][4];
 #pragma unroll
                     for (int ks2 = 0; ks2 < 2; ++ks2) {
                         fq[ks2] = lds_r128(sm, R3_Q + aq[ks2]);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) fk[ks2][t] = lds_r128(sm, R3_K + ak[ks2] + t * 2048);   // (all of them: a definition on every path)
+                        for (int t = 0; t < 4; ++t) if (NM == 0 || on(t)) fk[ks2][t] = lds_r128(sm, R3_K + ak[ks2] + t * 2048);   // (run-time form: all of them, a definition on every path)
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) pr[t] = zero4();
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     for (int ks2 = 0; ks2 < 2; ++ks2) {
                         fdo[ks2] = lds_r128(sm, R3_DO + aq[ks2]);
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) fv[ks2][t] = lds_r128(sm, R3_V + ak[ks2] + t * 2048);
+                        for (int t = 0; t < 4; ++t) if (NM == 0 || on(t)) fv[ks2][t] = lds_r128(sm, R3_V + ak[ks2] + t * 2048);
                     }
 #pragma unroll
                     for (int t = 0; t < 4; ++t) dp[t] = zero4();
@@ -401,8 +405,16 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 }
             };
             if (!(MSST_B3_EXP & 16)) {
-                if (L == 64) softmax_phase(std::false_type{});
-                else softmax_phase(std::true_type{});
+                if (L == 64) softmax_phase(std::integral_constant<int, -1>{});
+                else switch (need) {   // (wave uniform, tile invariant)
+                    case 0x3: softmax_phase(std::integral_constant<int, 0x3>{}); break;
+                    case 0x7: softmax_phase(std::integral_constant<int, 0x7>{}); break;
+                    case 0xe: softmax_phase(std::integral_constant<int, 0xe>{}); break;
+                    case 0xc: softmax_phase(std::integral_constant<int, 0xc>{}); break;
+                    case 0x6: softmax_phase(std::integral_constant<int, 0x6>{}); break;
+                    case 0xf: softmax_phase(std::integral_constant<int, 0xf>{}); break;
+                    default: softmax_phase(std::integral_constant<int, 0>{}); break;
+                }
             }
         }
         STAMP(4);
