@@ -37,6 +37,9 @@
 #ifndef MSST_B3_EXP
 #define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = no row requests
 #endif
+#ifndef MSST_B4_HASH_P1
+#define MSST_B4_HASH_P1 1   // the attention-probability dropout hash is issued between the MFMAs of phase 1 (0: inside the softmax phase)
+#endif
 #ifndef MSST_B4_LAG
 #define MSST_B4_LAG 2   // barriers head B runs behind head A (1 or 2; 3 would need a second OUT buffer)
 #endif
@@ -281,6 +284,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #endif
         R4_STAMP(0);
         B4_PRIO(1);
+        // keep decisions of the attention-probability dropout (site 1) of this lane's 16 scores of phase 2, bit 4 t + r: the hash
+        // needs no data, so it is issued here, between the MFMAs of phase 1 (which leave the VALU idle), instead of in the
+        // VALU-bound softmax phase
+        unsigned keepm = 0;
+        unsigned p2a[3];   // the softmax phase's lane addresses, computed under phase 1's MFMAs as well
         // ---------------- phase 1: q | k | v | dO = rows . W^T  (C[i = channel][j = row], stored [row][channel]) ----------------
         {
             const int t_ = launder3(tid);
@@ -305,7 +313,22 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     c[0][1] = mma32(w1[0][ks], fb[ks % 3][1], c[0][1]);
                     c[1][0] = mma32(w1[1][ks], fb[ks % 3][0], c[1][0]);
                     c[1][1] = mma32(w1[1][ks], fb[ks % 3][1], c[1][1]);
+                    if (DROP && ks < 4 && MSST_B4_HASH_P1) {
+                        unsigned ha, hb;
+                        drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + (t_ & 15)) * 16 + ks * 4 + ((t_ >> 4) & 3)), ha, hb);
+                        const unsigned t16 = a.drop.thr << 16;
+                        keepm |= ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
+                                  ((unsigned)(hb >= t16) << 3)) << (4 * ks);
+                    }
                 });
+            {
+                const int l = t_ & 63, g = l >> 4, c16 = l & 15, fzc = fz(c16);
+                p2a[0] = gb + c16 * 128 + ((g ^ fzc) << 4);          // (gb: no bits below 16 K, commutes with the XORs)
+                p2a[1] = gb + c16 * 128 + (((4 + g) ^ fzc) << 4);
+                p2a[2] = gb + (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p2a[i]));
+            }
             const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -328,15 +351,14 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             typedef PBF16 P;
             const int t_ = launder3(tid);
             const int l = t_ & 63, g = l >> 4, c16 = l & 15;
-            const int fzc = fz(c16);
             const int qlo = 16 * wave + c16 - (int)(rowmap[16 * wave + c16] & 0xffffu), qhi = qlo + L;   // keys of this query's sequence
             unsigned ak[2], aq[2];   // A operand rows 16 t + c16 (k, v), B operand rows 16 wave + c16 (q, dO); k-step ks2
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
-                ak[ks2] = gb + c16 * 128 + (((4 * ks2 + g) ^ fzc) << 4);   // (gb: no bits below 16 K, commutes with the XORs)
+                ak[ks2] = p2a[ks2];
                 aq[ks2] = ak[ks2] + wave * 2048;
             }
-            const unsigned L8 = gb + (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);   // ^ (t << 5)
+            const unsigned L8 = p2a[2];   // ^ (t << 5)
             // Short sequences (spectral blocks): a wave's 16 queries only meet the key tiles that overlap their own sequences -- bit t
             // of `need` (wave uniform, tile invariant).  Every other 16 x 16 score tile is masked anyway and is skipped altogether
             // (operand reads, MFMAs, exps, dropout hashes); its P / dS entries are stored as zeros.
@@ -414,13 +436,15 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     pr[t] = pr[t] * inv;
                     f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                     if (DROP) {
-                        unsigned ha, hb;
-                        drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
-                        const unsigned t16 = a.drop.thr << 16;
-                        dm[t][0] = (ha << 16) >= t16 ? a.drop.scale : 0.f;
-                        dm[t][1] = ha >= t16 ? a.drop.scale : 0.f;
-                        dm[t][2] = (hb << 16) >= t16 ? a.drop.scale : 0.f;
-                        dm[t][3] = hb >= t16 ? a.drop.scale : 0.f;
+                        if (!MSST_B4_HASH_P1) {
+                            unsigned ha, hb;
+                            drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
+                            const unsigned t16 = a.drop.thr << 16;
+                            keepm = ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
+                                     ((unsigned)(hb >= t16) << 3)) << (4 * t);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) dm[t][r] = (keepm >> (4 * t + r)) & 1u ? a.drop.scale : 0.f;
                         pd = pd * dm[t];
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
