@@ -300,8 +300,10 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pre = hp[nt][r] + lnp[192 + n0 + r];
-                hv[r] = P::gelu(pre);
-                dv[r] = dhm[r] * P::gelu_grad(pre);
+                float gv, gg;
+                P::gelu_both(pre, gv, gg);
+                hv[r] = gv;
+                dv[r] = dhm[r] * gg;
             }
             if (a.drop.thr && valid) hv = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hv);        // site 3 forward
             P::st_nat(&sm.h[wave * 16][nt * 16], LDH, hv);

@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(pr[t][r], cs, -mc)); pr[t][r] = e; sum += e; }
                 }
                 sum = colgroup_sum(sum);
-                const float inv = 1.f / sum;
+                const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (!on(t)) { lds_w64(sm, R3_P + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }

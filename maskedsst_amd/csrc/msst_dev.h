@@ -42,6 +42,7 @@ __device__ __forceinline__ float gelu_erf(float x);
 __device__ __forceinline__ float gelu_erf_grad(float x);
 __device__ __forceinline__ float gelu_fast(float x);
 __device__ __forceinline__ float gelu_fast_grad(float x);
+__device__ __forceinline__ void gelu_fast_both(float x, float& g, float& dg);
 
 // ------------------------------------------------------------------------------------------
 // precision policies
@@ -61,6 +62,7 @@ struct PF32 {
     static __device__ __forceinline__ float exp(float x) { return expf(x); }
     static __device__ __forceinline__ float gelu(float x) { return gelu_erf(x); }
     static __device__ __forceinline__ float gelu_grad(float x) { return gelu_erf_grad(x); }
+    static __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) { g = gelu_erf(x); dg = gelu_erf_grad(x); }
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
@@ -120,6 +122,7 @@ struct PBF16 {
     static __device__ __forceinline__ float exp(float x) { return __expf(x); }   // v_exp_f32; probabilities are rounded to bf16 anyway
     static __device__ __forceinline__ float gelu(float x) { return gelu_fast(x); }
     static __device__ __forceinline__ float gelu_grad(float x) { return gelu_fast_grad(x); }
+    static __device__ __forceinline__ void gelu_both(float x, float& g, float& dg) { gelu_fast_both(x, g, dg); }
     static __device__ __forceinline__ f32x4 mma(frag a, frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(
             __builtin_bit_cast(__attribute__((ext_vector_type(8))) __bf16, a),
@@ -372,7 +375,7 @@ __device__ __forceinline__ f32x4 drop4_bits(const Drop& d, unsigned keep, f32x4 
 // ~250-cycle libm erff; used by the bf16 kernels (the fp32 parity kernels keep erff)
 __device__ __forceinline__ float erf_fast(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);   // (v_rcp_f32, 1 ulp: __frcp_rn is a ten-instruction IEEE division)
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float r = 1.0f - poly * __expf(-ax * ax);
     return copysignf(r, x);
@@ -382,6 +385,17 @@ __device__ __forceinline__ float gelu_fast_grad(float x) {
     const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
     const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
+}
+
+// value and derivative together (MLP backward): the erf's exp(-(x / sqrt 2)^2) IS the density's exp(-x^2 / 2) -- one v_exp, not two
+__device__ __forceinline__ void gelu_fast_both(float x, float& g, float& dg) {
+    const float ax = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float e = __expf(-ax * ax);
+    const float cdf = 0.5f * (1.0f + copysignf(1.0f - poly * e, x));
+    g = x * cdf;
+    dg = cdf + x * (0.39894228040143267794f * e);
 }
 
 __device__ __forceinline__ f32x4 zero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }

@@ -329,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[t][r], cs, -mc)); s[t][r] = e; sum += e; }
                 sum = colgroup_sum(sum);
-                const float inv = (DROP ? a.drop.scale : 1.f) / sum;   // the dropout scale rides on the normalisation
+                const float inv = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(sum);   // the dropout scale rides on the normalisation
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     s[t] = s[t] * inv;
@@ -375,7 +375,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                     }
                 }
                 sum = colgroup_sum(sum);
-                const float inv = (DROP ? a.drop.scale : 1.f) / sum;
+                const float inv = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(sum);
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if ((nm >> t) & 1u) {

@@ -14,11 +14,6 @@ python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.tx
 # box microbenchmark (MFMA / HBM / L2 / LDS access patterns)
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/peak_microbench.hip -o /tmp/peak_microbench && /tmp/peak_microbench > $OUT/peak_microbench.json
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1 || true
-find $OUT/stats -name "*kernel_trace.csv" -delete
-timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err || true
-tail -1 $OUT/bench_default.json | cut -c1-600
-timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
 B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline"
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- $B > /dev/null 2>&1 || true
@@ -30,6 +25,14 @@ python3 tools/pmc_summary.py $OUT/pmc_WRITE_SIZE > $OUT/pmc_write.txt
 ( python3 tools/pmc_summary.py $OUT/pmc_sq1; python3 tools/pmc_summary.py $OUT/pmc_sq2 ) > $OUT/pmc_sq.txt
 grep -A1 "block_" $OUT/pmc_fetch.txt || true; grep -A1 "block_" $OUT/pmc_write.txt || true
 find $OUT -name "*.csv" -size +512k -delete
+# the per-launch HBM traffic table bench.py quotes (roofline.traffic, hbm_bound_kernels) comes from these passes: write it in
+# place BEFORE the bench lines below are taken, so that the committed line and the committed table belong to the same kernels
+python3 tools/make_profiles.py "$TAG" --traffic-only
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1 || true
+find $OUT/stats -name "*kernel_trace.csv" -delete
+timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err || true
+tail -1 $OUT/bench_default.json | cut -c1-600
+timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
 # other configurations (parity-test shapes and the batch sweep), one line each
 ( python3 bench.py --no-cpu-baseline --dropout 0 | tail -1
   python3 bench.py --no-cpu-baseline --bands 50 | tail -1

@@ -32,6 +32,8 @@ json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pa
                      "--batch 256 (tools/final_prof.sh), final kernels of the round",
            "correction": "FETCH_SIZE x2 (gfx950 16B/lane streaming under-report, MI355X_MICROARCH.md), WRITE_SIZE x1; KB -> bytes",
            "kernels": kern}, open(os.path.join(DST, f"{tag}_pmc_traffic.json"), "w"), indent=1)
+if "--traffic-only" in sys.argv:
+    raise SystemExit(0)
 shutil.copy(os.path.join(SRC, "stats", f"{tag}_kernel_stats.csv"), os.path.join(DST, f"{tag}_kernel_stats_bench_b256.csv"))
 shutil.copy(os.path.join(SRC, "bench_default.json"), os.path.join(DST, f"{tag}_bench_default.json"))
 shutil.copy(os.path.join(SRC, "bench_profile_all.json"), os.path.join(DST, f"{tag}_bench_b256_events.json"))
