@@ -39,6 +39,7 @@ extern "C" {
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
 #define MSST_KERNEL_ATTN_R2 (32 << 8)    /* bf16 attention backward: the round-2 kernel (16x16x32 tiles)     */
+#define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 
 #define MSST_MODE_SPATIAL 0  /* sequences = (b, c), N tokens each, contiguous            */
 #define MSST_MODE_SPECTRAL 1 /* sequences = (b, n), S tokens each, stride N*96 floats    */
@@ -141,10 +142,11 @@ typedef struct MsstBlockGrads {
 
 /* Backward of one fused block: given the saved block input x, the saved mid residual x1 and dy,
  * writes dx and every parameter gradient of the block.  Internally: MLP half (recompute from x1)
- * -> attention half, one workgroup per (tile chunk, head), weight grads in registers -> LN1
- * backward + residual; partial-gradient slabs are reduced in a fixed order (deterministic).
+ * -> attention half, one workgroup per (tile chunk, head) -- or per (tile chunk, head PAIR): the default bf16 kernel for an
+ * even head count -- weight grads in registers -> LN1 backward + residual; partial-gradient slabs are reduced in a fixed
+ * order (deterministic).
  * Workspace (caller-owned, device): dx1 [tokens][96] f32; dxn_part heads*tokens*96 elems
- * (f32 or bf16 by prec); slab grid_rows*(2*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB
+ * (f32 or bf16 by prec; the head-pair kernel uses the first half); slab grid_rows*(2*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB
  * floats (the bf16 MLP half runs up to 2*grid_rows workgroups, one slab each). */
 int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/, const float* x,
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,

@@ -1439,9 +1439,9 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
     } else if (!(a.dbg & 16)) {
         // MSST_DBG=16 selects the template kernel below (reference for the tuned ones), 32 the round-2 tuned kernel
-        // 64 the one-head-per-workgroup round-3 kernel; default: two heads per workgroup (msst_bwd4.hip)
+        // 128 the one-head-per-workgroup round-3 kernel; default: two heads per workgroup (msst_bwd4.hip)
         if (!(a.dbg & 32) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) {
-            if (!(a.dbg & 64) && !(a.H & 1)) { *nparts = a.H / 2; return launch_block_bwd_attn_r4(a, nchunk, st); }
+            if (!(a.dbg & 128) && !(a.H & 1)) { *nparts = a.H / 2; return launch_block_bwd_attn_r4(a, nchunk, st); }
             return launch_block_bwd_attn_r3(a, nchunk, st);
         }
         return launch_block_bwd_attn_bf16(a, nchunk, st);

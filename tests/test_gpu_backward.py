@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 CASES = [
     dict(bands=20, depth=1, B=2, heads=2),
     dict(bands=30, depth=1, B=3, heads=2, tube_masking=False),
+    dict(bands=20, depth=1, B=2, heads=3),   # odd head count: the one-head-per-workgroup attention backward (msst_bwd3.hip)
     dict(bands=50, depth=2, B=4),
     dict(bands=50, depth=2, B=4, spectral_pos_embed=True),
     dict(bands=50, depth=2, B=4, to_pixels_per_spectral_block=False, mask_patch_size=1),
@@ -119,10 +120,10 @@ def test_param_grads_bf16(cfg):
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
 @pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
-@pytest.mark.parametrize("tuned", [0, 64, 32], ids=["r4", "r3", "r2"])
+@pytest.mark.parametrize("tuned", [0, 128, 32], ids=["r4", "r3", "r2"])
 def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
     """The tuned bf16 attention backward kernels -- round 3, two heads per workgroup (msst_bwd4.hip; the default), round 3, one
-    head per workgroup (msst_bwd3.hip: one GEMM per wave, 32x32x16 MFMAs, swizzled LDS tiles; MSST_DBG=64, and the fallback for
+    head per workgroup (msst_bwd3.hip: one GEMM per wave, 32x32x16 MFMAs, swizzled LDS tiles; MSST_DBG=128, and the fallback for
     an odd head count) and round 2 (msst_bwd2.hip, MSST_DBG=32), all fed with the LN1 rows saved by the forward and the
     pre-dropped bf16 da rows left by the MLP half -- against the template kernel (msst_bwd.hip, MSST_DBG=16; re-reads
     x / dx1, renormalises, applies the to_out dropout itself): same bf16 operands and the same dropout masks up to summation
@@ -159,5 +160,5 @@ def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
         worst = max(worst, e)
         if not e < bar_g:
             bad.append((name, e))
-    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), kernel={0: "r4", 64: "r3", 32: "r2"}[tuned], dx=e_dx, worst_grad=worst)
+    record("attn_bwd_kernels_agree", cfg=cfg, drop=list(drop), kernel={0: "r4", 128: "r3", 32: "r2"}[tuned], dx=e_dx, worst_grad=worst)
     assert not bad, bad

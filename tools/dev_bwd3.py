@@ -103,7 +103,7 @@ def main():
             return dx0.clone(), eng.fp.grad.clone()
 
         dx_new, g_new = run(0)
-        dx_r2, g_r2 = run(64)   # the one-head-per-workgroup kernel
+        dx_r2, g_r2 = run(128)   # the one-head-per-workgroup kernel
         dx_t, g_t = run(16)
         print(f"== drop {drop}: dx new vs r2 {rel_l2(dx_new, dx_r2):.3e}  new vs template {rel_l2(dx_new, dx_t):.3e}  r2 vs template {rel_l2(dx_r2, dx_t):.3e}")
         worst = []
@@ -127,9 +127,9 @@ def main():
         tdrop = (0.0, 0) if "nodrop" in sys.argv else (0.1, 5)
         out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=tdrop)
         dy = torch.randn_like(out["enc_out"]) * 1e-3
-        res = {0: [], 64: []}
+        res = {0: [], 128: []}
         for rnd in range(4):
-            for flag in (0, 64):
+            for flag in (0, 128):
                 os.environ["MSST_DBG"] = str(flag)
                 eng.lib.msst_profile_enable(1)
                 for _ in range(8):
@@ -143,7 +143,7 @@ def main():
                 d = {eng.lib.msst_profile_name(i).decode(): round(1e3 * tot[i] / max(cnt[i], 1), 1) for i in range(n) if cnt[i]}
                 if rnd:
                     res[flag].append(d)
-        for flag in (0, 64):
+        for flag in (0, 128):
             print("flag", flag, {k: min(r[k] for r in res[flag]) for k in res[flag][0]})
         os.environ["MSST_DBG"] = "0"
 
