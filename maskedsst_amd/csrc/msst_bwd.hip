@@ -296,7 +296,8 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
             const int n0 = nt * 16 + 4 * g;
             f32x4 hv, dv;
             f32x4 dhm = dh[nt];
-            if (a.drop.thr && valid) dhm = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), dhm);   // site 3 backward
+            unsigned keep3 = 0xfu;   // site 3: one hash for the backward mask here and the forward mask below
+            if (a.drop.thr && valid) dhm = drop4_keep(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), dhm, keep3);   // site 3 backward
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pre = hp[nt][r] + lnp[192 + n0 + r];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
                 hv[r] = gv;
                 dv[r] = dhm[r] * gg;
             }
-            if (a.drop.thr && valid) hv = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hv);        // site 3 forward
+            if (a.drop.thr && valid) hv = drop4_bits(a.drop, keep3, hv);                                  // site 3 forward
             P::st_nat(&sm.h[wave * 16][nt * 16], LDH, hv);
             P::st_nat(&sm.dhp[wave * 16][nt * 16], LDH, dv);
         }

@@ -1,0 +1,8 @@
+# A/B of whole-step kernel times: rebuild with the given -D flags (one quoted string per variant) and print the per-kernel event times of bench.py
+for e in "$@"; do
+  python -c "from maskedsst_amd.build import build; build(force=True, extra_flags=tuple('$e'.split()))" > /dev/null 2>&1
+  echo "== $e"; python bench.py --no-cpu-baseline --no-pipeline --profile-all --steps 8 2>/dev/null | tail -1 | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read())
+print(d['ms_per_step'], {k:v['avg_us'] for k,v in d['kernels'].items() if k.startswith('block')})"
+done
