@@ -35,7 +35,8 @@
 #define MSST_B3_W1AT 8   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
 #endif
 #ifndef MSST_B3_EXP
-#define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = no row requests
+#define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = every row
+                        // request reads token 0, 16 = no softmax phase, 32 = no phase 4, 64 = no weight-gradient GEMM, 256 = no barriers, 1024 = no copy-out
 #endif
 #ifndef MSST_B4_HASH_P1
 #define MSST_B4_HASH_P1 1   // the attention-probability dropout hash is issued between the MFMAs of phase 1 (0: inside the softmax phase)
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (grp && tile != (int)blockIdx.x) copy_out();
+        if (!(MSST_B3_EXP & 1024) && grp && tile != (int)blockIdx.x) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
