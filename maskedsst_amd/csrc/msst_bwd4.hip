@@ -183,10 +183,14 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         for (int t = 0; t < 4; ++t) m |= (unsigned)(16 * t <= khi && 16 * t + 15 >= klo) << t;
         need = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     }
-    // row-wise LDS address of this thread's j-th 16-byte slot (row tid / 4, logical slot 3 (tid % 4) + j) in a 96-wide tile
+    // row-wise LDS address of this thread's j-th 16-byte slot in a 96-wide tile: row tid / 4, logical slot 4 j + tid % 4 -- the four
+    // threads of a row cover 64 contiguous bytes per store instruction (MSST_B4_COSEG = 0: 3 (tid % 4) + j, 16-byte pieces 48 bytes apart)
+#ifndef MSST_B4_COSEG
+#define MSST_B4_COSEG 1
+#endif
     auto row_slot = [&](int j) -> unsigned {
         const int t_ = launder3(tid);
-        const int row = t_ >> 2, s = 3 * (t_ & 3) + j;
+        const int row = t_ >> 2, s = MSST_B4_COSEG ? 4 * j + (t_ & 3) : 3 * (t_ & 3) + j;
         return (unsigned)(row * 192 + (((s & ~3) | ((s & 3) ^ fz2(row))) << 4));
     };
     // The LN1(x) / da rows of the NEXT tile go straight from HBM into the other row buffer (LDS-DMA, head A's waves: 1 KB per
@@ -243,7 +247,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     {
         const unsigned sp = rowmap[tid >> 2];
         csx = (unsigned)(R4_SEQO + 4 * min((int)(sp >> 16), 64));
-        cinv = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)(tid & 3) * 48u;
+        cinv = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)(tid & 3) * (MSST_B4_COSEG ? 16u : 48u);
     }
     auto copy_out = [&]() {
         const int bs = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sm + csx);
@@ -251,9 +255,9 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
         for (int j = 0; j < 3; ++j) v[j] = *reinterpret_cast<const lds_u32x4*>(sm + R4_OUT + row_slot(j));
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(a.ntok * 192), 0x00020000);
-        const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + cinv;   // (+ 32 must not wrap)
+        const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + cinv;   // (+ 128 must not wrap)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 16 * j, 0, 0);
+        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + (MSST_B4_COSEG ? 64 : 16) * j, 0, 0);
     };
     // phase-1 weight fragments [d tile][k step]: tile invariant, but 48 registers the softmax phase has no room for -- all twelve
     // are re-requested from L2 during phase 4 of the tile before (the rows no longer pass registers: a ring of eight refilled
