@@ -39,7 +39,7 @@
                         // request reads token 0, 16 = no softmax phase, 32 = no phase 4, 64 = no weight-gradient GEMM, 256 = no barriers, 1024 = no copy-out
 #endif
 #ifndef MSST_B4_HASH_P1
-#define MSST_B4_HASH_P1 1   // the attention-probability dropout hash is issued between the MFMAs of phase 1 (0: inside the softmax phase)
+#define MSST_B4_HASH_P1 1   // the attention-probability dropout hash of all four key tiles is issued at the top of the softmax phase (0: per key tile, behind the softmax)
 #endif
 #ifndef MSST_B4_LAG
 #define MSST_B4_LAG 2   // barriers head B runs behind head A (1 or 2; 3 would need a second OUT buffer)
@@ -289,11 +289,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #endif
         R4_STAMP(0);
         B4_PRIO(1);
-        // keep decisions of the attention-probability dropout (site 1) of this lane's 16 scores of phase 2, bit 4 t + r: the hash
-        // needs no data, so it is issued here, between the MFMAs of phase 1 (which leave the VALU idle), instead of in the
-        // VALU-bound softmax phase
-        unsigned keepm = 0;
-        unsigned p2a[3];   // the softmax phase's lane addresses, computed under phase 1's MFMAs as well
+        unsigned keepm = 0;   // keep decisions of the attention-probability dropout (site 1) of this lane's 16 scores of phase 2, bit 4 t + r
+        unsigned p2a[4];   // the softmax phase's lane addresses and first key of the lane's sequence, computed under phase 1's MFMAs as well
         // ---------------- phase 1: q | k | v | dO = rows . W^T  (C[i = channel][j = row], stored [row][channel]) ----------------
         {
             const int t_ = launder3(tid);
@@ -318,21 +315,15 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     c[0][1] = mma32(w1[0][ks], fb[ks % 3][1], c[0][1]);
                     c[1][0] = mma32(w1[1][ks], fb[ks % 3][0], c[1][0]);
                     c[1][1] = mma32(w1[1][ks], fb[ks % 3][1], c[1][1]);
-                    if (DROP && ks < 4 && MSST_B4_HASH_P1) {
-                        unsigned ha, hb;
-                        drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + (t_ & 15)) * 16 + ks * 4 + ((t_ >> 4) & 3)), ha, hb);
-                        const unsigned t16 = a.drop.thr << 16;
-                        keepm |= ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
-                                  ((unsigned)(hb >= t16) << 3)) << (4 * ks);
-                    }
                 });
             {
                 const int l = t_ & 63, g = l >> 4, c16 = l & 15, fzc = fz(c16);
                 p2a[0] = gb + c16 * 128 + ((g ^ fzc) << 4);          // (gb: no bits below 16 K, commutes with the XORs)
                 p2a[1] = gb + c16 * 128 + (((4 + g) ^ fzc) << 4);
                 p2a[2] = gb + (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);
+                p2a[3] = (unsigned)(16 * wave + c16 - (int)(rowmap[16 * wave + c16] & 0xffffu));
 #pragma unroll
-                for (int i = 0; i < 3; ++i) asm volatile("" : "+v"(p2a[i]));
+                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(p2a[i]));
             }
             const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
 #pragma unroll
@@ -356,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             typedef PBF16 P;
             const int t_ = launder3(tid);
             const int l = t_ & 63, g = l >> 4, c16 = l & 15;
-            const int qlo = 16 * wave + c16 - (int)(rowmap[16 * wave + c16] & 0xffffu), qhi = qlo + L;   // keys of this query's sequence
+            const int qlo = (int)p2a[3], qhi = qlo + L;   // keys of this query's sequence
             unsigned ak[2], aq[2];   // A operand rows 16 t + c16 (k, v), B operand rows 16 wave + c16 (q, dO); k-step ks2
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
@@ -372,6 +363,19 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int t = 0; t < 4; ++t) dm[t] = zero4();
             const float cs = a.scale * 1.44269504088896340736f;   // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e
+            // The dropout hash needs no data: all four key tiles' keep bits first, while the phase's operand reads are in flight,
+            // instead of 12 quarter-rate multiplies inside the dependent chain max -> exp -> sum -> P.  (Issued under phase 1's MFMAs
+            // -- the VALU is idle there too -- it cost 2 %: phase 1 is on the critical path of its barrier interval.)
+            if (DROP && MSST_B4_HASH_P1) {
+                const unsigned t16 = a.drop.thr << 16;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    unsigned ha, hb;
+                    drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
+                    keepm |= ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
+                              ((unsigned)(hb >= t16) << 3)) << (4 * t);
+                }
+            }
             // NM: -1 = one 64-token sequence, nothing masked; > 0 = short sequences, the key tiles of this wave known at compile
             // time (straight-line code: the run-time form below breaks the phase into thirty basic blocks and costs 1.5 k cycles);
             // 0 = short sequences, key tiles from `need` at run time (patterns without an instance)
