@@ -45,6 +45,10 @@
                            // through an opaque scalar register): hoisted out of the tile loop they were 178 SGPRs spilled to VGPR lanes,
                            // i.e. ~190 v_readlane per wave and tile in a kernel whose limiter is the VALU stream
 #endif
+#ifndef MSST_F2_EXP
+#define MSST_F2_EXP 0   // timing experiments (wrong results): 1 = every q / k / v weight request reads the same two fragments, 2 = no softmax
+                        // arithmetic (scores pass through), 8 = every out-projection weight request reads fragment 0
+#endif
 #ifndef MSST_F2_SKIP
 #define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
 #endif
@@ -104,7 +108,10 @@ __device__ __forceinline__ frag ld_w_gather(const elem* w, int K, int row32, int
 //   12..17 gathered v  (pair = low / high channel halves of block mm at k-step ks; pi = 12 + 3 mm + ks)
 __device__ __forceinline__ void load_pair(int pi, frag (&out)[2], const elem* wqkv, const elem* wout, int H, int h,
                                           const int (&voff)[2]) {
-    if (pi < 12) {
+    if (MSST_F2_EXP & 1) {
+        out[0] = P::ld_w(wqkv, 96, 0, 0);
+        out[1] = P::ld_w(wqkv, 96, 16, 0);
+    } else if (pi < 12) {
         const int st = pi / 3, ks = pi % 3;
         const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
         out[0] = P::ld_w(wqkv, 96, r0, ks * 32);
@@ -314,6 +321,14 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                     s[t] = P::mma(kA[t][0], qB[j][0], zero4());   // C[i = key][j = query]
                     s[t] = P::mma(kA[t][1], qB[j][1], s[t]);
                 }
+                if (MSST_F2_EXP & 2) {
+                    const frag p0 = pack2(s[0], s[1]), p1 = pack2(s[2], s[3]);
+#pragma unroll
+                    for (int dd = 0; dd < 4; ++dd) {
+                        o[dd] = P::mma(vA[dd][0], p0, zero4());
+                        o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+                    }
+                } else {
                 // softmax over the 64 keys.  exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e: one FMA + one v_exp
                 // per element, nothing to mask
                 float mx = -INFINITY;
@@ -341,6 +356,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 for (int dd = 0; dd < 4; ++dd) {
                     o[dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
                     o[dd] = P::mma(vA[dd][1], p1, o[dd]);
+                }
                 }
             } else {
                 // several short sequences per tile: keys outside the query's own sequence are masked; key tiles that no row of
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
+            for (int i = 0; i < 3; ++i) fw[s8][i] = (MSST_F2_EXP & 8) ? P::ld_w(wout, inner, 0, 0) : P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
         lds_barrier();   // O complete
         STAMP(11);
         // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------
