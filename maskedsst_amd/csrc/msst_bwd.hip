@@ -1200,6 +1200,8 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
     if (tid < 96) bias[tid] = a.b_emb[c * 96 + tid];
     const int n = tid >> 2, part = tid & 3;
+    // this thread's 24 features, as in tokenize_fwd_kernel: the four threads of a token read 64 contiguous bytes per instruction
+    auto feat = [&](int i) { return 16 * (i >> 2) + 4 * part + (i & 3); };
     const bool active = n < N;
     // (the mask-token gradient of this thread's slots is dpos - dpb: every token adds its dt to dpos, the unmasked ones also
     // to dpb -- one accumulator set less, the kernel sits at the 256-register limit)
@@ -1224,9 +1226,9 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
         f32x4 drow[6];
         {
             const int tc = c * N + (active ? n : 0);
-            const f32x4* dsrc = reinterpret_cast<const f32x4*>(a.dx0 + ((long)b * T + tc) * 96 + part * 24);
+            const float* dsrc = a.dx0 + ((long)b * T + tc) * 96 + part * 4;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) drow[i] = dsrc[i];
+            for (int i = 0; i < 6; ++i) drow[i] = *reinterpret_cast<const f32x4*>(dsrc + 16 * i);
         }
         if (active) {
             const int t = c * N + n;
@@ -1235,7 +1237,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
                 f32x4 t4 = drow[i];
-                if (a.drop.thr) t4 = drop4(a.drop, 0, (unsigned)(((long)b * T + t) * 24 + part * 6 + i), t4);   // emb dropout backward
+                if (a.drop.thr) t4 = drop4(a.drop, 0, (unsigned)(((long)b * T + t) * 24 + 4 * i + part), t4);   // emb dropout backward (group = feature / 4)
                 dt[4*i] = t4[0]; dt[4*i+1] = t4[1]; dt[4*i+2] = t4[2]; dt[4*i+3] = t4[3];
             }
 #pragma unroll
@@ -1259,7 +1261,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < 24; ++i) {
-                const int d = part * 24 + i;
+                const int d = feat(i);
                 float acc = bias[d];
 #pragma unroll
                 for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
@@ -1277,7 +1279,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             float g1 = 0.f, g2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 24; ++i) {
-                const int d = part * 24 + i;
+                const int d = feat(i);
                 const float eh = (e[i] - m2) * rstd2;
                 e[i] = eh;
                 if (masked) dt[i] = 0.f;
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             for (int k = 0; k < 16; ++k) dxn[k] = 0.f;
 #pragma unroll
             for (int i = 0; i < 24; ++i) {
-                const int d = part * 24 + i;
+                const int d = feat(i);
                 const float de = rstd2 * (dt[i] - g1 - e[i] * g2);
                 dbc[i] += de;
                 de_s[n][d] = de;
@@ -1327,7 +1329,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     float* slab = a.slab + ((long)c * gridDim.y + chunk) * slab_n;
     if (active) {
 #pragma unroll
-        for (int i = 0; i < 24; ++i) slab[n * 96 + part * 24 + i] = dpos[i];
+        for (int i = 0; i < 24; ++i) slab[n * 96 + feat(i)] = dpos[i];
     }
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -1340,7 +1342,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
 #pragma unroll
         for (int i = 0; i < 24; ++i) {
             const float v = which == 0 ? dbc[i] : which == 1 ? dpg[i] : which == 2 ? dpb[i] : dpos[i] - dpb[i];
-            de_s[n][part * 24 + i] = active ? v : 0.f;
+            de_s[n][feat(i)] = active ? v : 0.f;
         }
         __syncthreads();
         if (tid < 96) {

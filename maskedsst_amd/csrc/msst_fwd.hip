@@ -47,12 +47,15 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     const float rstd = rsqrtf(var / P + 1e-5f);
 #pragma unroll
     for (int k = 0; k < P; ++k) xn[k] = (patch[k][n] - mean) * rstd * a.pre_g[k] + a.pre_b[k];
-    // per-block Linear(P -> 96): this thread's 24 features
+    // per-block Linear(P -> 96): this thread's 24 features 16 (i / 4) + 4 part + i % 4 -- the four threads of a token then store 64
+    // contiguous bytes per instruction (24 consecutive features per thread made every store instruction hit four 16-byte pieces
+    // 96 bytes apart per token)
+    auto feat = [&](int i) { return 16 * (i >> 2) + 4 * part + (i & 3); };
     float e[24];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
-        const int d = part * 24 + i;
+        const int d = feat(i);
         float acc = bias[d];
 #pragma unroll
         for (int k = 0; k < P; ++k) acc += W[d][k] * xn[k];
@@ -68,10 +71,10 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     const float rstd2 = rsqrtf(v2 * (1.f / 96.f) + 1e-5f);
     const int t = c * N + n;
     const bool masked = a.mask[(long)b * a.T + t] != 0;
-    float* dst = a.out + ((long)b * a.T + t) * 96 + part * 24;
+    float* dst = a.out + ((long)b * a.T + t) * 96 + part * 4;
 #pragma unroll
     for (int i = 0; i < 24; ++i) {
-        const int d = part * 24 + i;
+        const int d = feat(i);
         float pos;
         if (a.pos_split) pos = d < a.pos_split ? a.pos_a[n * a.pos_split + d] : a.pos_b[c * (96 - a.pos_split) + d - a.pos_split];
         else pos = a.pos_a[(long)t * 96 + d];
@@ -81,8 +84,8 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         f32x4 v = {e[4*i], e[4*i+1], e[4*i+2], e[4*i+3]};
-        if (a.drop.thr) v = drop4(a.drop, 0, (unsigned)(((long)b * a.T + t) * 24 + part * 6 + i), v);   // emb dropout
-        reinterpret_cast<f32x4*>(dst)[i] = v;
+        if (a.drop.thr) v = drop4(a.drop, 0, (unsigned)(((long)b * a.T + t) * 24 + 4 * i + part), v);   // emb dropout (group = feature / 4)
+        *reinterpret_cast<f32x4*>(dst + 16 * i) = v;
     }
 }
 
