@@ -1195,10 +1195,12 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     __shared__ float de_s[64][97];
     __shared__ float xn_s[64][17];
     __shared__ float bias[96];
+    __shared__ float postg[96], preg[16], preb[16];   // small parameter vectors read inside the batch walk: from LDS, not through L2
     const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x;
     const int P = PC ? PC : a.P, N = a.N, T = a.T;
     for (int i = tid; i < 96 * P; i += 256) W[i / P][i % P] = a.w_emb[(long)c * 96 * P + i];
-    if (tid < 96) bias[tid] = a.b_emb[c * 96 + tid];
+    if (tid < 96) { bias[tid] = a.b_emb[c * 96 + tid]; postg[tid] = a.post_g[tid]; }
+    if (tid < 16) { preg[tid] = tid < P ? a.pre_g[tid] : 0.f; preb[tid] = tid < P ? a.pre_b[tid] : 0.f; }
     const int n = tid >> 2, part = tid & 3;
     // this thread's 24 features, as in tokenize_fwd_kernel: the four threads of a token read 64 contiguous bytes per instruction
     auto feat = [&](int i) { return 16 * (i >> 2) + 4 * part + (i & 3); };
@@ -1254,7 +1256,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
             const float rstd = rsqrtf(var / P + 1e-5f);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                if (k < P) { xh0[k] = (patch[k][n] - mean) * rstd; xn[k] = xh0[k] * a.pre_g[k] + a.pre_b[k]; }
+                if (k < P) { xh0[k] = (patch[k][n] - mean) * rstd; xn[k] = xh0[k] * preg[k] + preb[k]; }
                 else { xh0[k] = 0.f; xn[k] = 0.f; }
             }
             float e[24];
@@ -1285,7 +1287,7 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
                 if (masked) dt[i] = 0.f;
                 dpg[i] += dt[i] * eh;
                 dpb[i] += dt[i];
-                dt[i] *= a.post_g[d];
+                dt[i] *= postg[d];
                 g1 += dt[i];
                 g2 += dt[i] * eh;
             }
