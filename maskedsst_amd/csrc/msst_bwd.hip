@@ -93,6 +93,15 @@ __global__ __launch_bounds__(256) void reduce_segs_kernel(RSegs r) {
         if (i < g.n) {
             const float* p = g.src + i;
             int k = sg;
+            // long slab lists (the 512 slabs of the two-workgroups-per-CU MLP backward) with sixteen requests in flight: with four, a
+            // block walked 16 serial HBM round trips and the launch took as long as its slowest block
+            for (; k + 120 < g.nslab; k += 128) {
+                f32x4 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long)(k + 8 * u) * g.slab_stride);
+#pragma unroll
+                for (int u = 0; u < 16; ++u) s = s + v[u];
+            }
             for (; k + 24 < g.nslab; k += 32) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long)k * g.slab_stride);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long)(k + 8) * g.slab_stride);
