@@ -11,6 +11,7 @@ CASES = [
     dict(bands=20, depth=1, B=2, heads=2),
     dict(bands=30, depth=1, B=3, heads=2, tube_masking=False),
     dict(bands=20, depth=1, B=2, heads=3),   # odd head count: the one-head-per-workgroup attention backward (msst_bwd3.hip)
+    dict(bands=20, depth=1, B=3, heads=4),   # two head pairs per tile chunk, three cubes: a partial last spectral tile
     dict(bands=50, depth=2, B=4),
     dict(bands=50, depth=2, B=4, spectral_pos_embed=True),
     dict(bands=50, depth=2, B=4, to_pixels_per_spectral_block=False, mask_patch_size=1),
