@@ -10,8 +10,9 @@ pytestmark = pytest.mark.gpu
 CASES = [
     dict(bands=20, depth=1, B=2, heads=2),
     dict(bands=30, depth=1, B=3, heads=2, tube_masking=False),
-    dict(bands=20, depth=1, B=2, heads=3),   # odd head count: the one-head-per-workgroup attention backward (msst_bwd3.hip)
-    dict(bands=20, depth=1, B=3, heads=4),   # two head pairs per tile chunk, three cubes: a partial last spectral tile
+    dict(bands=20, depth=1, B=2, heads=3),   # head counts other than 8: the 4-wave forward and the template attention backward
+    dict(bands=20, depth=1, B=3, heads=4),   # (the tuned backward kernels at these head counts: test_attn_bwd_tuned_kernels_other_head_counts)
+    dict(bands=10, depth=1, B=2, heads=2),   # one spectral token: 64 one-row sequences per spectral tile (the run-time key-tile form of the softmax phase)
     dict(bands=50, depth=2, B=4),
     dict(bands=50, depth=2, B=4, spectral_pos_embed=True),
     dict(bands=50, depth=2, B=4, to_pixels_per_spectral_block=False, mask_patch_size=1),
@@ -119,7 +120,7 @@ def test_param_grads_bf16(cfg):
 
 
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
-@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)],
+@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4), dict(bands=10, depth=1, B=4, heads=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 @pytest.mark.parametrize("tuned", [0, 128, 32], ids=["r4", "r3", "r2"])
 def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
@@ -198,3 +199,47 @@ def test_attn_bwd_two_head_vs_one_head_at_bench_batch(monkeypatch):
     record("attn_bwd_two_head_vs_one_head_b256", dx=e_dx, worst_grad=worst)
     assert e_dx < 6e-4, e_dx        # measured 2.9e-4
     assert worst < 4.6e-3, worst    # measured 2.3e-3
+
+
+@pytest.mark.parametrize("heads", [2, 3, 4, 6])
+def test_attn_bwd_tuned_kernels_other_head_counts(heads, monkeypatch):
+    """The engine saves LN1 rows only from the head-per-wave forward (8 heads), so with other head counts the tuned attention
+    backward kernels are reached only by a caller that hands msst_block_bwd its own `xn_saved` rows.  This test is such a caller:
+    LN1(x) computed in torch, rounded to bf16, attached to the saved activations; then the two-head kernel (even head counts:
+    one, two and three head pairs per tile chunk) or the one-head kernel (3 heads) against the template kernel."""
+    cfg = dict(bands=50, depth=1, B=3, heads=heads)
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    drop = (0.1, 99)
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+    for i, (sname, l) in enumerate(eng._layers()):
+        assert getattr(out["x1s"][i], "_msst_xn", None) is None   # (the 4-wave forward does not save them)
+        g = eng.fp.view(f"{sname}.{l}.ln1_g", eng.fp.flat).float()
+        b = eng.fp.view(f"{sname}.{l}.ln1_b", eng.fp.flat).float()
+        xin = out["acts"][i].float()
+        out["x1s"][i]._msst_xn = torch.nn.functional.layer_norm(xin, (96,), g, b, 1e-5).to(torch.bfloat16).contiguous()
+
+    def run(flag):
+        monkeypatch.setenv("MSST_DBG", str(flag))
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=drop)
+        torch.cuda.synchronize()
+        return dx0.clone(), eng.fp.grad.clone()
+
+    dx_new, g_new = run(0)
+    dx_old, g_old = run(16)
+    monkeypatch.delenv("MSST_DBG")
+    e_dx = rel_l2(dx_new, dx_old)
+    worst = 0.0
+    for name, p in eng.trainable():
+        ref = eng.fp.view(name, g_old)
+        if float(ref.abs().max()) == 0.0:
+            continue
+        worst = max(worst, rel_l2(eng.fp.view(name, g_new), ref))
+    record("attn_bwd_tuned_other_head_counts", heads=heads, dx=e_dx, worst_grad=worst)
+    assert e_dx > 0.0, "the tuned kernel did not run (identical to the template)"
+    # measured: two-head kernel 4.0e-4 / 2.4e-3 (one bf16 partial per head pair), one-head kernel 1.3e-5 / 1.3e-4 (the template's rounding points)
+    bar_dx, bar_g = (8e-4, 4.8e-3) if heads % 2 == 0 else (1e-4, 5e-4)
+    assert e_dx < bar_dx, e_dx
+    assert worst < bar_g, worst
