@@ -120,7 +120,7 @@ def test_param_grads_bf16(cfg):
 
 
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 1234)], ids=["nodrop", "drop0.1"])
-@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4), dict(bands=10, depth=1, B=4, heads=4)],
+@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4), dict(bands=10, depth=1, B=4)],
                          ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 @pytest.mark.parametrize("tuned", [0, 128, 32], ids=["r4", "r3", "r2"])
 def test_attn_bwd_kernels_agree(cfg, drop, tuned, monkeypatch):
