@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
                 wa[m][ks] = P::ld_w(wqkv, 96, (m * H + 0) * 64 + wave * 16, ks * 32);
         // ---------------- LN1 from the prefetched rows ----------------
         {
+            const long tok_ln1 = a.xn_out ? tm.token_sp(tile, sp_ln) : -1;
             float v[24];
 #pragma unroll
             for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
@@ -456,7 +457,10 @@ __global__ __launch_bounds__(256, 2) void block_fwd_bf16_kernel(BlockArgs a) {
                 f32x4 n4;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[part * 24 + 4*i+e] + lnp[96 + part * 24 + 4*i+e];
-                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 24 + 4 * i]) = f2bf4(n4);
+                const s16x4 nb = f2bf4(n4);
+                *reinterpret_cast<s16x4*>(&sm.xn[lr][part * 24 + 4 * i]) = nb;
+                // the same bf16 rows go to HBM for the tuned attention backward kernels (as in block_fwd_hw_kernel)
+                if (a.xn_out && tok_ln1 >= 0) *reinterpret_cast<s16x4*>(reinterpret_cast<bf16_t*>(a.xn_out) + tok_ln1 * 96 + part * 24 + 4 * i) = nb;
             }
         }
         STAMP(1);
@@ -803,7 +807,7 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
 }
 
 bool block_fwd_writes_xn(const BlockArgs& a, int prec) {
-    return prec == MSST_PREC_BF16 && !(a.dbg & 16) && a.H == 8 && !(a.dbg & 64);   // = the head-per-wave kernel is selected above
+    return prec == MSST_PREC_BF16 && !(a.dbg & 16);   // both tuned bf16 kernels (head-per-wave for 8 heads, 4-wave otherwise) store their LN1 rows
 }
 
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st) {
