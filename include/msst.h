@@ -102,8 +102,9 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
  * dropout_p > 0 enables the reference's four dropout sites (:38,40,57,62) with a stateless counter-based
  * mask keyed by (seed, layer, site, element); msst_block_bwd regenerates it from the same three values.
  * xn_out (optional, [tokens][96] bf16): receives LN1(x) exactly as the block used it, so that msst_block_bwd neither
- * re-reads x nor renormalises it; *xn_written (host, optional) tells whether the selected kernel wrote it (only the
- * bf16 head-per-wave kernel does) -- pass xn_saved to msst_block_bwd only then. */
+ * re-reads x nor renormalises it; *xn_written (host, optional) tells whether the selected kernel wrote it (the two tuned
+ * bf16 kernels do -- head-per-wave for 8 heads, 4-wave otherwise; the fp32 and MSST_KERNEL_GENERIC kernels do not) -- pass
+ * xn_saved to msst_block_bwd only then. */
 int msst_block_fwd(const MsstBlockWeights* w /*host*/, const float* x, float* y, float* x1, int mode,
                    int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed,
                    int layer, void* xn_out, int* xn_written /*host*/, void* stream);
