@@ -53,6 +53,14 @@
 #define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
 #endif
 
+#ifndef MSST_F2_STAMPSEL
+#define MSST_F2_STAMPSEL 0x00c09   // which of the stamps 0 .. 17 a -DMSST_STAMPS build carries.  All of them at once make the kernel spill to scratch, and
+                                   // a spill reload waits for every prefetch in flight: phase times of such a build are artefacts.  Subsets that compile
+                                   // without spills: 0x00c09 (tile start, LN1 done, attention done, O barrier passed), 0x3f001 (tile start, out-projection
+                                   // ... end); check `grep -c scratch_` of the -save-temps assembly before trusting another one
+#endif
+#define F2_STAMP(i) do { if ((MSST_F2_STAMPSEL >> (i)) & 1) STAMP(i); } while (0)
+
 namespace msst {
 
 namespace {
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #ifdef MSST_STAMPS
         const bool stamp_on = stamp_wg && tile == blockIdx.x + 8 * (int)gridDim.x;   // a mid-walk tile
 #endif
-        STAMP(0);
+        F2_STAMP(0);
         int t1 = threadIdx.x;
         asm volatile("" : "+v"(t1));
         const int lr = t1 >> 3, part = t1 & 7;
@@ -261,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 for (int ks = 0; ks < 3; ++ks) xf[t][ks] = P::ld_kc(&sm.xn[t * 16][ks * 32], LDX);
 #pragma unroll
             for (int st = 0; st < 6; ++st) {
-                STAMP(3 + st);
+                F2_STAMP(3 + st);
                 if (st < 4) {
                     // q and k: C[i = channel][j = row]; channel tiles (2m, 2m+1) -> k-chunk m of the operand
                     const int m = st & 1;
@@ -307,7 +315,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 }
             }
         }
-        STAMP(9);
+        F2_STAMP(9);
         if (MSST_F2_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         // ================= attention of head h for the four query tiles; O rows go to the shared bf16 tile =================
 #pragma unroll
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             *reinterpret_cast<frag*>(orow) = pack2(o[0], o[1]);
             *reinterpret_cast<frag*>(orow + 32) = pack2(o[2], o[3]);
         }
-        STAMP(10);
+        F2_STAMP(10);
         // rows owned from here on: lane (c, g) of wave (tt, half) <-> row 16 tt + c, features 16 (3 half + i) + 4 g .. + 3.
         // Residual values of this tile (L2 hits) and the next tile's rows for LN1 are requested now: q / k / v registers are
         // free.  Per-thread indices are re-derived from a laundered lane id so that none stays live across the head phase.
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
             for (int i = 0; i < 3; ++i) fw[s8][i] = (MSST_F2_EXP & 8) ? P::ld_w(wout, inner, 0, 0) : P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
         lds_barrier();   // O complete
-        STAMP(11);
+        F2_STAMP(11);
         // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------
         f32x4 acc[2][3];   // [row tile 2 rh + jj][feature tile 3 mh + i]
 #pragma unroll
@@ -478,9 +486,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 for (int i = 0; i < 3; ++i) dst[i * 64] = acc[0][i];
             }
         }
-        STAMP(12);
+        F2_STAMP(12);
         lds_barrier();
-        STAMP(13);
+        F2_STAMP(13);
         // ---------------- bias, dropout, residual -> x1;  LN2 -> xn  (all in registers) ----------------
         f32x4 x1r[3];   // x1 of the owned rows / features: stays in registers until the end of the MLP
         {
@@ -521,9 +529,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 *reinterpret_cast<s16x4*>(&sm.xn[tt * 16 + c3][m0]) = f2bf4(n4);
             }
         }
-        STAMP(14);
+        F2_STAMP(14);
         lds_barrier();
-        STAMP(15);
+        F2_STAMP(15);
         // ---------------- MLP: wave <-> (row tile tt, half of the outputs) ----------------
         {
             f32x4 hh[2];
@@ -579,10 +587,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
                 }
             }
         }
-        STAMP(16);
+        F2_STAMP(16);
         // no barrier at the end of the tile: the next LN1 writes xn, last read before the barrier that precedes the second
         // MLP GEMM; ob / xch / st / hb are rewritten only after later barriers of the next tile
-        STAMP(17);
+        F2_STAMP(17);
     }
 }
 

@@ -1,4 +1,5 @@
-"""kernel study: cycle stamps of one wave of block_fwd_hw (MSST_DBG=8; stamps build, see tools/stamps.py)."""
+"""kernel study: cycle stamps of one wave of block_fwd_hw (MSST_DBG=8; stamps build, see tools/stamps.py).
+Build with -DMSST_STAMPS -DMSST_F2_STAMPSEL=0x00c09 or 0x3f001 (subsets that do not spill) and -DMSST_F2_STAMP_TID=<thread>."""
 import os, sys, ctypes
 os.environ["MSST_DBG"] = "8"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +22,6 @@ names = ["tile start", "-", "-", "q m=0 start", "q m=1", "k m=0", "k m=1", "v mm
          "barrier", "MLP (1 barrier inside)", "end"]
 prev = s[0]
 for i, n in enumerate(names):
-    if n == '-': continue
+    if n == '-' or (i and s[i] == 0): continue   # (stamps not compiled in: MSST_F2_STAMPSEL)
     print(f"{n:18s} +{s[i]-prev:7d}  (t={s[i]-s[0]})")
     prev = s[i]
