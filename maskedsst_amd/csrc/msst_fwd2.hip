@@ -47,7 +47,8 @@
 #endif
 #ifndef MSST_F2_EXP
 #define MSST_F2_EXP 0   // timing experiments (wrong results): 1 = every q / k / v weight request reads the same two fragments, 2 = no softmax
-                        // arithmetic (scores pass through), 8 = every out-projection weight request reads fragment 0
+                        // arithmetic (scores pass through), 8 = every out-projection weight request reads fragment 0, 16 = no token arithmetic (every tile reads and
+                        // writes the rows of tile 0)
 #endif
 #ifndef MSST_F2_SKIP
 #define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
@@ -85,6 +86,8 @@ struct Fwd2Smem {
     f32x4 xch[8][3][64];                  // K-half exchange: [receiving wave][C tile][lane]
     float2 st[8][16];                     // LN2 partial statistics (mean, M2 over 48 features): [wave][row in tile]
     elem hb[64][LDH];                     // GELU(W1 .) of the MLP
+    unsigned rowmap[64];                  // tile row -> (sequence slot << 16 | position), 0xffff = padding row: tile invariant
+    int seqb[2][64];                      // token of position 0 of every sequence slot of the tile being processed / the next one (by tile parity)
 };
 
 __device__ __forceinline__ int sopaque(int v) {
@@ -171,6 +174,35 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 
     // row-wise phases (LN1, residual + LN2): thread <-> (row tid / 8, 12 features)
     const int2 sp_ln = tm.row_sp(tid >> 3);
+    // Token arithmetic through two small LDS tables instead of two integer divisions per thread, three times per tile (420 instructions
+    // between the last wave's attention and the "O complete" barrier): the row map is tile invariant, the sequence bases of a tile are
+    // computed by 64 threads one tile ahead.
+#ifndef MSST_F2_TOKTAB
+#define MSST_F2_TOKTAB 1
+#endif
+    auto fill_seq = [&](int par, int tile_) {
+        if (tid < 64) {
+            const int q = tile_ * tm.TS + tid;
+            int base = -1;
+            if (tile_ < a.ntiles && tid < tm.TS && q < tm.nseq) {
+                if (tm.mode == 0) base = q * tm.N;
+                else { const int b = tm.nshift >= 0 ? (q >> tm.nshift) : q / tm.N; base = b * tm.T + (q - b * tm.N); }
+            }
+            sm.seqb[par][tid] = base;
+        }
+    };
+    auto tok_of = [&](int par, int r) -> long {
+        const unsigned sp = sm.rowmap[r];
+        const int base = sm.seqb[par][min((int)(sp >> 16), 63)];
+        return ((sp >> 16) == 0xffffu || base < 0) ? -1 : (long)(base + (int)(sp & 0xffffu) * (tm.mode == 0 ? 1 : tm.N));
+    };
+    if (tid < 64) {
+        const int sq = tid / L, ps = tid - sq * L;
+        sm.rowmap[tid] = ((unsigned)(sq >= tm.TS ? 0xffff : sq) << 16) | (unsigned)ps;
+    }
+    fill_seq(0, blockIdx.x);
+    __syncthreads();
+    int par = 0;
     // out-projection: wave <-> (feature half mh, row-tile pair rh, K half kh); it ends up owning row tile tt = 2 rh + kh
     // of feature half mh, and keeps that role through LN2 and the MLP
     const int mh = wave & 1, rh = (wave >> 1) & 1, kh = wave >> 2;
@@ -218,7 +250,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
     const bool stamp_wg = (a.dbg & 8) && blockIdx.x == 100 && tid == MSST_F2_STAMP_TID;
 #endif
     if (MSST_F2_PRIO == 1 && wave >= 4) __builtin_amdgcn_s_setprio(1);   // the later-dispatched half loses every age arbitration otherwise
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, par ^= 1) {
 #ifdef MSST_STAMPS
         const bool stamp_on = stamp_wg && tile == blockIdx.x + 8 * (int)gridDim.x;   // a mid-walk tile
 #endif
@@ -231,7 +263,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             float v[12];
 #pragma unroll
             for (int i = 0; i < 3; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
-            const long tok_ln = tm.token_sp(tile, tm.row_sp(lr));
+            if (MSST_F2_TOKTAB) fill_seq(par ^ 1, tile + (int)gridDim.x);   // (read behind the "O complete" barrier and by the next tile)
+            const long tok_ln = (MSST_F2_EXP & 16) ? (long)lr : MSST_F2_TOKTAB ? tok_of(par, lr) : tm.token_sp(tile, tm.row_sp(lr));
             if (tok_ln < 0) {   // padding row: the prefetch read a clamped address, normalise zeros
 #pragma unroll
                 for (int i = 0; i < 12; ++i) v[i] = 0.f;
@@ -431,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
         int l3 = threadIdx.x & 63;
         asm volatile("" : "+v"(l3));
         const int g3 = l3 >> 4, c3 = l3 & 15;
-        const long tok = tm.token_sp(tile, tm.row_sp(tt * 16 + c3));
+        const long tok = (MSST_F2_EXP & 16) ? (long)(tt * 16 + c3) : MSST_F2_TOKTAB ? tok_of(par, tt * 16 + c3) : tm.token_sp(tile, tm.row_sp(tt * 16 + c3));
         f32x4 xr[3];
         {
             const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 48 * half + 4 * g3;
@@ -440,7 +473,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
             int t2 = threadIdx.x;
             asm volatile("" : "+v"(t2));
             const int nt = tile + gridDim.x;
-            const long tokn = nt < a.ntiles ? tm.token_sp(nt, tm.row_sp(t2 >> 3)) : -1;
+            const long tokn = (MSST_F2_EXP & 16) ? (long)(t2 >> 3) : MSST_F2_TOKTAB ? tok_of(par ^ 1, t2 >> 3) : nt < a.ntiles ? tm.token_sp(nt, tm.row_sp(t2 >> 3)) : -1;
             const float* xn_row = a.x + (tokn >= 0 ? tokn : 0) * 96 + (t2 & 7) * 12;
 #pragma unroll
             for (int i = 0; i < 3; ++i) xv[i] = reinterpret_cast<const f32x4*>(xn_row)[i];
