@@ -48,7 +48,7 @@
 #ifndef MSST_F2_EXP
 #define MSST_F2_EXP 0   // timing experiments (wrong results): 1 = every q / k / v weight request reads the same two fragments, 2 = no softmax
                         // arithmetic (scores pass through), 8 = every out-projection weight request reads fragment 0, 16 = no token arithmetic (every tile reads and
-                        // writes the rows of tile 0)
+                        // writes the rows of tile 0), 32 / 64 = as 8, for the waves of the second / first K half only
 #endif
 #ifndef MSST_F2_SKIP
 #define MSST_F2_SKIP 0   // measured: skipping the masked score tiles of spectral blocks costs more in branches than it saves (+1.5 %)
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_hw_kernel(BlockArgs a) {
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
-            for (int i = 0; i < 3; ++i) fw[s8][i] = (MSST_F2_EXP & 8) ? P::ld_w(wout, inner, 0, 0) : P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
+            for (int i = 0; i < 3; ++i) fw[s8][i] = ((MSST_F2_EXP & 8) || ((MSST_F2_EXP & 32) && kh == 1) || ((MSST_F2_EXP & 64) && kh == 0)) ? P::ld_w(wout, inner, 0, 0) : P::ld_w(wout, inner, (3 * sopaque(mh) + i) * 16, (8 * sopaque(kh) + s8) * 32);
         lds_barrier();   // O complete
         F2_STAMP(11);
         // ---------------- out-projection: C[i = feature][j = row], K = 512 split in two ----------------
