@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSST_VERSION 100
+#define MSST_VERSION 101
 #define MSST_DIM 96
 #define MSST_DIM_HEAD 64
 #define MSST_MLP 64
@@ -156,6 +156,25 @@ int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /
                    void* dab_ws /*optional workspace [tokens][96] bf16, used together with xn_saved: the MLP half leaves the
                                   dropped bf16 copy of dx1 there for the attention half*/,
                    void* stream);
+
+/* The same backward for a RUN of blocks (bf16 throughput path): called once per block in reverse order, it fuses the row-local
+ * seam BETWEEN consecutive blocks -- the LN1 backward of block i and the MLP-half backward of block i - 1
+ * (vit_spatial_spectral.py:22-44,102-103 are row-local) run as ONE launch, so dx of block i never reaches HBM:
+ *   first != 0 (the last block of the model = first call): its MLP half runs on dy first (dy -> dx1, dab_ws);
+ *   every call: attention half of block i on the dx1 / dab_ws rows left by the step above or by the previous call;
+ *   w_prev != NULL: LN1 backward of block i + MLP half of block i - 1 (weights w_prev, saved mid residual x1_prev; its
+ *       parameter gradients go to g_prev): dx1 and dab_ws are overwritten IN PLACE with block i - 1's; dx is not touched;
+ *   w_prev == NULL (block 0): the LN1 backward runs alone and writes dx.
+ * Gradients of block i are complete when the call for block i returns (its MLP-half gradients were written by the call
+ * before).  Requires prec = MSST_PREC_BF16 (tuned kernels), xn_saved and dab_ws, and at most four d(LN1 out) partials
+ * (heads <= 8 even, or heads <= 4): MSST_ERR_BADARG / MSST_ERR_UNSUPPORTED otherwise -- use msst_block_bwd then.
+ * slab: grid_rows*(3*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB floats.  x1 is read only when first != 0. */
+int msst_block_bwd_chain(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/,
+                         const MsstBlockWeights* w_prev /*host, block i - 1 or NULL*/, const MsstBlockGrads* g_prev /*host*/,
+                         const float* x, const float* x1, const float* x1_prev, const float* dy, float* dx, float* dx1,
+                         void* dxn_part, float* slab, int grid_rows, int nchunk, int mode, int B, int S, int N, int heads,
+                         int prec, float dropout_p, uint32_t seed, int layer, const void* xn_saved, void* dab_ws,
+                         int first, void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.
  * slab: S * nchunk * (N*96 + 96*P + 4*96 + 32) floats + S*N*96 floats (position staging).

@@ -176,7 +176,7 @@ int msst_profile_kernels(void) { return K_COUNT; }
 const char* msst_profile_name(int id) {
     static const char* names[K_COUNT] = {"prep_weights", "tokenize_fwd", "block_fwd", "head_fwd", "loss_reduce",
                                          "head_bwd", "reduce_slabs", "block_bwd_mlp", "block_bwd_attn",
-                                         "attn_slab_reduce", "block_bwd_ln1", "tokenize_bwd", "pos_split", "adamw"};
+                                         "attn_slab_reduce", "block_bwd_ln1", "tokenize_bwd", "pos_split", "adamw", "block_bwd_ln1mlp"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -287,13 +287,16 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
     return fail(rc, "msst_head_bwd(reduce)");
 }
 
-int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
-                   const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
-                   int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                   uint32_t seed, int layer, const void* xn_saved, void* dab_ws, void* stream) {
+// chain == 0: the three halves of ONE block (MLP half -> attention half -> LN1 backward), msst_block_bwd.
+// chain != 0: msst_block_bwd_chain (see include/msst.h): [MLP half of block i when `first`] -> attention half of block i ->
+//             LN1 backward of block i fused with the MLP half of block i - 1 (w_prev), or alone (block 0).
+static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, const MsstBlockWeights* w_prev,
+                          const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
+                          const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
+                          int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
+                          uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int chain, int first, hipStream_t st) {
     if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
-    hipStream_t st = (hipStream_t)stream;
     const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
     prec &= 0xff;
     const long ntok = (long)B * S * N;
@@ -311,10 +314,14 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
     aa.ntiles = ntiles_of(aa.tm);
     const int nc = nchunk < aa.ntiles ? nchunk : aa.ntiles;
     float* slab_ln1 = slab_attn + (long)nc * heads * MSST_ATTN_SLAB_N;
+    float* slab_mlp_prev = slab_ln1 + (long)grid * MSST_LN1_SLAB;   // chain: the fused launch's MLP slabs (block i - 1), one per workgroup
     // saved LN1 rows + pre-dropped bf16 da rows: both or neither, and only for the tuned bf16 attention kernel
     const bool fast_rows = xn_saved && dab_ws && prec == MSST_PREC_BF16 && !(dbg & 16);
+    if (chain && (!fast_rows || (w_prev && (!g_prev || !x1_prev)) || (first && !dy) || (!w_prev && !dx)))
+        return fail(MSST_ERR_BADARG, "msst_block_bwd_chain (bf16 with saved LN1 rows and the dab workspace only)");
+    const bool run_mlp = !chain || first;
     // 1. MLP half: dy -> dx1
-    {
+    if (run_mlp) {
         MlpBwdArgs a;
         a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok; a.drop = drop;
         a.dab = fast_rows ? dab_ws : nullptr;
@@ -336,23 +343,41 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
         int rc = launch_block_bwd_attn(aa, nc, prec, st, &nparts);
         if (rc) return fail(rc, "msst_block_bwd(attn)");
     }
-    // 3. LN1 backward + residual
-    {
+    // 3. LN1 backward + residual -- alone, or fused with the MLP half of the block before (dx stays on chip)
+    const bool fused = chain && w_prev;
+    if (fused) {
+        if (nparts > 4) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd_chain (more than four d(LN1 out) partials)");
+        LnMlpArgs a;
+        a.w = to_bw(w_prev); a.ln1_g = w->ln1_g; a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.x1 = x1_prev; a.dab = dab_ws;
+        a.slab_mlp = slab_mlp_prev; a.slab_ln1 = slab_ln1; a.ntok = ntok; a.nparts = nparts;
+        a.drop_i = drop; a.drop_p = make_drop(dropout_p, seed, layer - 1);
+        a.stamps = nullptr;
+#ifdef MSST_STAMPS
+        a.stamps = g_stamps;
+#endif
+        int rc = launch_block_bwd_ln1mlp(a, grid, st);
+        if (rc) return fail(rc, "msst_block_bwd_chain(ln1 + mlp)");
+    } else {
         Ln1BwdArgs a;
         a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.ln1_g = w->ln1_g; a.dx = dx; a.slab = slab_ln1; a.ntok = ntok; a.H = nparts; a.drop = drop;
         int rc = launch_block_bwd_ln1(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(ln1)");
     }
-    // 4. one deterministic reduction of all partial-gradient slabs of the block
+    // 4. one deterministic reduction of all partial-gradient slabs written above
     {
         RSegBuilder rb;
         const long ms = MSST_MLP_SLAB_N;
-        bool ok = rb.add(slab_mlp, ms, grid_mlp, g->w1, 6144);
-        ok = ok && rb.add(slab_mlp + 6144, ms, grid_mlp, g->w2, 6144);
-        ok = ok && rb.add(slab_mlp + 12288, ms, grid_mlp, g->b1, 64);
-        ok = ok && rb.add(slab_mlp + 12288 + 64, ms, grid_mlp, g->b2, 96);
-        ok = ok && rb.add(slab_mlp + 12288 + 160, ms, grid_mlp, g->ln2_g, 96);
-        ok = ok && rb.add(slab_mlp + 12288 + 256, ms, grid_mlp, g->ln2_b, 96);
+        bool ok = true;
+        auto add_mlp = [&](const float* sm_, int nslab, const MsstBlockGrads* gg) {
+            ok = ok && rb.add(sm_, ms, nslab, gg->w1, 6144);
+            ok = ok && rb.add(sm_ + 6144, ms, nslab, gg->w2, 6144);
+            ok = ok && rb.add(sm_ + 12288, ms, nslab, gg->b1, 64);
+            ok = ok && rb.add(sm_ + 12288 + 64, ms, nslab, gg->b2, 96);
+            ok = ok && rb.add(sm_ + 12288 + 160, ms, nslab, gg->ln2_g, 96);
+            ok = ok && rb.add(sm_ + 12288 + 256, ms, nslab, gg->ln2_b, 96);
+        };
+        if (run_mlp) add_mlp(slab_mlp, grid_mlp, g);
+        if (fused) add_mlp(slab_mlp_prev, grid, g_prev);
         ok = ok && rb.add(slab_ln1, 288, grid, g->ln1_g, 96);
         ok = ok && rb.add(slab_ln1 + 96, 288, grid, g->ln1_b, 96);
         ok = ok && rb.add(slab_ln1 + 192, 288, grid, g->bo, 96);
@@ -374,6 +399,23 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
         if (rc) return fail(rc, "msst_block_bwd(reduce)");
     }
     return 0;
+}
+
+int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
+                   const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
+                   int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
+                   uint32_t seed, int layer, const void* xn_saved, void* dab_ws, void* stream) {
+    return block_bwd_impl(w, g, nullptr, nullptr, x, x1, nullptr, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
+                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 0, 0, (hipStream_t)stream);
+}
+
+int msst_block_bwd_chain(const MsstBlockWeights* w, const MsstBlockGrads* g, const MsstBlockWeights* w_prev,
+                         const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
+                         const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
+                         int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
+                         uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int first, void* stream) {
+    return block_bwd_impl(w, g, w_prev, g_prev, x, x1, x1_prev, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
+                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 1, first, (hipStream_t)stream);
 }
 
 int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,

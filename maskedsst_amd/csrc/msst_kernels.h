@@ -107,6 +107,23 @@ struct Ln1BwdArgs {
     Drop drop;
 };
 
+// LN1 backward of block i fused with the MLP-half backward of block i - 1 (msst_bwd5.hip)
+struct LnMlpArgs {
+    BlockWeights w;          // block i - 1 (MLP half: w1, w1T, w2T, ln2_g, ln2_b, b1)
+    const float* ln1_g;      // block i
+    const float* x;          // [tokens][96] input of block i (= output of block i - 1)
+    float* dx1;              // in: dx1 of block i (gradient at its mid residual); out: dx1 of block i - 1 (same rows, in place)
+    const void* dxn_part;    // [nparts][tokens][96] bf16 partial d(LN1 out) of block i
+    const float* x1;         // [tokens][96] mid residual of block i - 1
+    void* dab;               // out: [tokens][96] bf16, dx1 of block i - 1 with the to_out dropout applied (attention half's operand)
+    float* slab_mlp;         // [grid][MSST_MLP_SLAB_N]
+    float* slab_ln1;         // [grid][288]
+    long ntok;
+    int nparts;
+    Drop drop_i, drop_p;     // dropout streams of block i (site 2) and of block i - 1 (sites 2, 3, 4)
+    unsigned long long* stamps;   // -DMSST_STAMPS builds: cycle stamps of the eight waves of one workgroup (tools/stamps_bwd5.py)
+};
+
 struct TokBwdArgs {
     const float* img; const float* pre_g; const float* pre_b; const float* w_emb; const float* b_emb;
     const float* post_g; const float* post_b; const uint8_t* mask; const float* dx0; float* slab;
@@ -117,7 +134,7 @@ struct TokBwdArgs {
 // ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum KernelId {
     K_PREP = 0, K_TOK_FWD, K_BLOCK_FWD, K_HEAD_FWD, K_LOSS_REDUCE, K_HEAD_BWD, K_REDUCE, K_BWD_MLP, K_BWD_ATTN,
-    K_ATTN_REDUCE, K_BWD_LN1, K_TOK_BWD, K_POS_SPLIT, K_ADAMW, K_COUNT
+    K_ATTN_REDUCE, K_BWD_LN1, K_TOK_BWD, K_POS_SPLIT, K_ADAMW, K_BWD_LN1MLP, K_COUNT
 };
 void prof_begin(int id, hipStream_t st);
 void prof_end(hipStream_t st);
@@ -173,6 +190,7 @@ int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st)
 int launch_block_bwd_attn_r3(const AttnBwdArgs& a, int nchunk, hipStream_t st);     // msst_bwd3.hip (bf16 throughput kernel: one GEMM per wave, 32x32x16 tiles)
 int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st);     // msst_bwd4.hip (the same, two heads per workgroup half a tile apart)
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);
+int launch_block_bwd_ln1mlp(const LnMlpArgs& a, int grid, hipStream_t st);   // msst_bwd5.hip (bf16: LN1 backward of block i + MLP backward of block i - 1)
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st);
 int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, float* dce, hipStream_t st);
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,

@@ -277,10 +277,38 @@ class Engine:
         dx1 = torch.empty(ntok * 96, dtype=torch.float32, device=dev)
         part = torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev)
         dab = torch.empty(ntok * 96, dtype=torch.bfloat16, device=dev) if self.prec != PREC_F32 else None
-        # the bf16 MLP backward runs two workgroups per CU: up to 2 * grid_rows MLP slabs (msst_block_bwd lays the parts out)
-        nslab = self.grid_rows * (2 * MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
+        # the bf16 MLP backward runs two workgroups per CU: up to 2 * grid_rows MLP slabs (msst_block_bwd lays the parts out);
+        # the chained form adds one MLP slab per workgroup of the fused LN1 + MLP launch
+        nslab = self.grid_rows * (3 * MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB
         slab = torch.empty(nslab, dtype=torch.float32, device=dev)
         layers = self._layers()
+        flags = _kernel_flags()
+        xns = [getattr(t, "_msst_xn", None) for t in x1s]
+        # Chained backward (msst_block_bwd_chain): the LN1 backward of block i and the MLP-half backward of block i - 1 are
+        # one launch, dx of block i stays on chip.  bf16 tuned kernels with saved LN1 rows only; at most four d(LN1 out)
+        # partials (one per head pair for an even head count, else one per head).
+        nparts = H // 2 if H % 2 == 0 else H
+        chain = (self.prec == PREC_BF16 and flags == 0 and dab is not None and all(t is not None for t in xns)
+                 and nparts <= 4 and os.environ.get("MSST_BWD_CHAIN", "1") != "0" and len(layers) > 0
+                 and ntok * 384 < 2 ** 31 - 16 and nparts * ntok * 192 < 2 ** 31 - 16)   # 32-bit buffer offsets in the fused launch
+        if chain:
+            last = len(layers) - 1
+            dx0 = torch.empty_like(dy)
+            null_w = ctypes.POINTER(MsstBlockWeights)()
+            null_g = ctypes.POINTER(MsstBlockGrads)()
+            for i in reversed(range(len(layers))):
+                sname, l = layers[i]
+                mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+                prev = i > 0
+                _lib.check(self.lib.msst_block_bwd_chain(
+                    ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]),
+                    ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
+                    _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
+                    _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode,
+                    B, S, N, H, self.prec, drop[0], drop[1], i, _p(xns[i]), _p(dab), 1 if i == last else 0, _stream()),
+                    "msst_block_bwd_chain")
+                self._fire(f"{sname}.{l}")
+            return dx0
         g = dy
         other = torch.empty_like(dy)
         for i in reversed(range(len(layers))):
@@ -289,8 +317,8 @@ class Engine:
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
-                self.prec | _kernel_flags(),
-                drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
+                self.prec | flags,
+                drop[0], drop[1], i, _p(xns[i]), _p(dab), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g
