@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--profile-all", action="store_true",
                     help="event pairs around every kernel in the timed region (default: only the dominant kernel, "
                          "found during warmup; ~150 event pairs per step cost ~5 %% of the step)")
+    ap.add_argument("--profile-every", type=int, default=5,
+                    help="timed region: HIP-event pairs around every n-th launch of the dominant kernel (1 = every launch)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of timed CPU steps per cpu_baseline leg")
     ap.add_argument("--cpu-leg", type=int, default=0, help=argparse.SUPPRESS)   # internal: run ONE cpu_baseline leg at this thread count
@@ -134,8 +136,8 @@ def main():
             # occupancy probe under the BACKWARD (that is where RCCL's channel workgroups run): starts when the forward is done,
             # holds its CUs for --thief-us; the optimizer step waits for it like it waits for the all-reduces
             thief["stream"].wait_stream(torch.cuda.current_stream())
-            lib.msst_debug_cu_thief(args.cu_thief, int(args.thief_us), ctypes.c_void_p(thief["sink"].data_ptr()),
-                                    ctypes.c_void_p(thief["stream"].cuda_stream))
+            _lib.check(lib.msst_debug_cu_thief(args.cu_thief, int(args.thief_us), ctypes.c_void_p(thief["sink"].data_ptr()),
+                                               ctypes.c_void_p(thief["stream"].cuda_stream)), "msst_debug_cu_thief")
         loss.backward()
         if reducer is not None:
             opt.grad_scale = reducer.finish()
@@ -171,6 +173,9 @@ def main():
         dom_name = max(cand, key=lambda k: cand[k]["total_ms"]) if cand else "block_bwd_attn"
         dom_id = [i for i in range(nk) if lib.msst_profile_name(i).decode() == dom_name][0]
         lib.msst_profile_select(ctypes.c_ulonglong(1 << dom_id))
+        # ... and only around every 5th launch of it (5 is coprime to the 24 launches of a step: spatial and spectral blocks are
+        # sampled alike): ~5 event pairs per step, < 0.2 % of it, instead of 24 (~1 %) -- the headline carries its own probe
+        lib.msst_profile_sample(args.profile_every)
     if world > 1:
         dist.barrier()
     if prof:
@@ -191,6 +196,7 @@ def main():
     elapsed = t1 - t0
     kernels = collect() if prof else {}
     lib.msst_profile_select(ctypes.c_ulonglong(2 ** 64 - 1))
+    lib.msst_profile_sample(1)
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -291,8 +297,9 @@ def main():
                                "traffic_source": traffic_source,
                                "avg_launch_us": round(cand[dom]["avg_us"], 2),
                                "algorithmic_gflop_per_launch": round(fl / 1e9, 3)}
-            out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches": v["launches"],
-                                  "share": round(v["total_ms"] / (1e3 * elapsed), 4)} for k, v in kernels.items()}
+            every = 1 if args.profile_all else max(1, args.profile_every)   # event pairs around every n-th launch only
+            out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches_timed": v["launches"], "timed_every": every,
+                                  "share": round(min(1.0, every * v["total_ms"] / (1e3 * elapsed)), 4)} for k, v in kernels.items()}
             # HBM-bound kernels: GB/s = committed PMC bytes per launch (same command) / this run's average launch time
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]

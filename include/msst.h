@@ -39,6 +39,7 @@ extern "C" {
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
 #define MSST_KERNEL_ATTN_R2 (32 << 8)    /* bf16 attention backward: the round-2 kernel (16x16x32 tiles)     */
+#define MSST_KERNEL_FWD_HW (256 << 8)    /* bf16 forward, 8 heads: the lockstep head-per-wave kernel (msst_fwd2.hip) instead of the role-split one (msst_fwd3.hip) */
 #define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 
 #define MSST_MODE_SPATIAL 0  /* sequences = (b, c), N tokens each, contiguous            */
@@ -55,8 +56,10 @@ typedef struct MsstPrepJob {
     const float* src; /* [rows][cols] fp32 master weight          */
     void* dst;        /* [rows][cols] or [cols][rows] (transpose) */
     int32_t rows, cols, transpose;
-    int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA),
-                         2 = as 1, and the first two thirds of the SOURCE rows (the q and k blocks of to_qkv) scaled by 2^-3 */
+    int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA;
+                         destination rows % 32 == 0 and k % 16 == 0).  Any other value: the job is skipped. */
+    int32_t scale_rows; /* the first scale_rows SOURCE rows are multiplied by `scale` (0: none).  The round-3 attention backward   */
+    float scale;        /* wants the q and k blocks of to_qkv^T pre-multiplied by dim_head^-0.5 (2^-3: exact in bf16).             */
 } MsstPrepJob;
 
 /* Converts / transposes all matrices of the model into operand layout in ONE launch.
@@ -66,6 +69,8 @@ int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int max_elems, int pre
 /* Operand-layout weights of one transformer block (device pointers).
  * Replaces the parameters of reference vit_spatial_spectral.py:85-97 (one Transformer layer). */
 typedef struct MsstBlockWeights {
+    uint64_t struct_bytes; /* = sizeof(MsstBlockWeights): a caller built against another revision of this header is refused
+                              (MSST_ERR_BADARG) instead of being read past the end of its struct */
     const void* wqkv;  /* [3*H*64][96]  to_qkv.weight, rows q|k|v, head-major */
     const void* wout;  /* [96][H*64]    to_out.0.weight                        */
     const void* w1;    /* [64][96]      net.0.weight                           */
@@ -80,7 +85,7 @@ typedef struct MsstBlockWeights {
      * attention backward feeds to 32x32x16 MFMAs, fragment-packed with MsstPrepJob.pack = 1 */
     const void* wqkv32;  /* [3*H*64][96]  */
     const void* woutT32; /* [H*64][96]    */
-    const void* wqkvT32; /* [96][3*H*64], pack = 2 (q and k blocks carry the softmax scale) */
+    const void* wqkvT32; /* [96][3*H*64], pack = 1, scale_rows = 2*H*64, scale = dim_head^-0.5 (q and k blocks carry the softmax scale) */
 } MsstBlockWeights;
 
 /* a1+a2+a3+a5: BlockwisePatchEmbedding.to_patch/.embed (vit_spatial_spectral.py:197-222), position
@@ -206,14 +211,16 @@ int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, f
  * the launch count since enable / the previous collect.  Thread-safe (mutex); meant for bench.py.
  * msst_debug_stamps: kernel-study builds (-DMSST_STAMPS) only; returns MSST_ERR_UNSUPPORTED otherwise. */
 int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tools/stamps.py */);
-/* Occupancy probe (diagnostic, bench.py --cu-thief): nblocks workgroups that only hold a CU slot each (256 threads, the full
- * register budget of two waves per SIMD and 64 KB of LDS, so that no MFMA workgroup fits beside one) for `microseconds`,
+/* Occupancy probe (diagnostic, bench.py --cu-thief): nblocks workgroups that only hold a CU each -- 256 threads and ALL 160 KB
+ * of the CU's LDS, so that no workgroup that uses LDS (every MFMA kernel of this library does) fits beside one -- for `microseconds`,
  * enqueued on `stream`; sink: 4 bytes of device scratch.  Stands in for the channel workgroups of an RCCL collective when
  * the overlap of the gradient all-reduce with the backward is studied on ONE GPU. */
 int msst_debug_cu_thief(int nblocks, int microseconds, void* sink, void* stream);
 int msst_profile_enable(int on);
 /* restrict the event pairs to the kernel ids whose bit is set (default: all); each pair costs ~10 us of stream time */
 int msst_profile_select(unsigned long long mask);
+/* bracket only every n-th launch of each selected kernel (default 1 = all): keeps the event pairs inside a timed region cheap */
+int msst_profile_sample(int every);
 int msst_profile_kernels(void);
 const char* msst_profile_name(int id);
 int msst_profile_collect(double* total_ms /*host*/, long* count /*host*/);

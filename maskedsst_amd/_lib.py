@@ -25,11 +25,11 @@ class MsstError(RuntimeError):
 
 class MsstPrepJob(Structure):
     _fields_ = [("src", c_void_p), ("dst", c_void_p), ("rows", c_int32), ("cols", c_int32),
-                ("transpose", c_int32), ("pack", c_int32)]
+                ("transpose", c_int32), ("pack", c_int32), ("scale_rows", c_int32), ("scale", c_float)]
 
 
 class MsstBlockWeights(Structure):
-    _fields_ = [(n, c_void_p) for n in (
+    _fields_ = [("struct_bytes", ctypes.c_uint64)] + [(n, c_void_p) for n in (
         "wqkv", "wout", "w1", "w2", "wqkvT", "woutT", "w1T", "w2T",
         "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2", "wqkv32", "woutT32", "wqkvT32")]
 
@@ -65,6 +65,7 @@ _SIGS = {
     "msst_debug_cu_thief": (c_int, [c_int, c_int, _P, _P]),
     "msst_profile_enable": (c_int, [c_int]),
     "msst_profile_select": (c_int, [ctypes.c_ulonglong]),
+    "msst_profile_sample": (c_int, [c_int]),
     "msst_profile_kernels": (c_int, []),
     "msst_profile_name": (c_char_p, [c_int]),
     "msst_profile_collect": (c_int, [_P, _P]),

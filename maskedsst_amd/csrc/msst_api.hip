@@ -24,6 +24,9 @@ static int fail(int code, const char* what) {
 template <class E>
 __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jobs) {
     const MsstPrepJob j = jobs[blockIdx.y];
+    // malformed jobs are skipped (the job table lives in device memory: the host entry point cannot validate it)
+    if (j.pack < 0 || j.pack > 1 || j.rows < 1 || j.cols < 1) return;
+    if (sizeof(E) == 2 && j.pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) return;
     const int n = j.rows * j.cols;
     E* dst = reinterpret_cast<E*>(j.dst);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
@@ -34,9 +37,9 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
             src_i = r * j.cols + c;
         }
         float v = j.src[src_i];
-        // pack 2 (to_qkv^T for the round-3 attention backward): the q and k blocks carry the softmax scale dim_head^-0.5 = 2^-3,
-        // exact in bf16 -- that kernel keeps dq / dk unscaled (reference vit_spatial_spectral.py:54,71)
-        if (j.pack == 2 && src_i / j.cols < 2 * (j.rows / 3)) v *= 0.125f;
+        // to_qkv^T for the round-3 attention backward: the q and k blocks (the first scale_rows source rows) carry the softmax scale
+        // dim_head^-0.5 = 2^-3, exact in bf16 -- that kernel keeps dq / dk unscaled (reference vit_spatial_spectral.py:54,71)
+        if (src_i / j.cols < j.scale_rows) v *= j.scale;
         if constexpr (sizeof(E) == 4) {
             dst[i] = v;
         } else {
@@ -68,6 +71,8 @@ static unsigned long long* g_stamps = nullptr;   // kernel-study builds only (py
 #endif
 static std::atomic<bool> g_prof_on{false};
 static std::atomic<unsigned long long> g_prof_mask{~0ull};   // kernels (bit = id) that get event pairs
+static std::atomic<int> g_prof_every{1};                      // ... every n-th launch of each (msst_profile_sample)
+static std::atomic<unsigned> g_prof_seen[K_COUNT];
 static std::mutex g_prof_mu;
 static std::vector<ProfRec> g_prof;
 static std::vector<hipEvent_t> g_pool;
@@ -86,6 +91,8 @@ static hipEvent_t pool_event() {
 void prof_begin(int id, hipStream_t st) {
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
     if (!((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1ull)) return;
+    const int every = g_prof_every.load(std::memory_order_relaxed);
+    if (every > 1 && g_prof_seen[id].fetch_add(1u, std::memory_order_relaxed) % (unsigned)every != 0u) return;
     ProfRec r;
     {
         std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -129,6 +136,8 @@ static Drop make_drop(float p, uint32_t seed, int layer) {
 
 static int ntiles_of(const TileMap& tm) { return (tm.nseq + tm.TS - 1) / tm.TS; }
 
+static bool bw_ok(const MsstBlockWeights* w) { return w && w->struct_bytes == sizeof(MsstBlockWeights); }
+
 static BlockWeights to_bw(const MsstBlockWeights* w) {
     BlockWeights b;
     b.wqkv = w->wqkv; b.wout = w->wout; b.w1 = w->w1; b.w2 = w->w2;
@@ -170,6 +179,13 @@ int msst_profile_enable(int on) {
 }
 
 int msst_profile_select(unsigned long long mask) { g_prof_mask.store(mask); return 0; }
+
+int msst_profile_sample(int every) {
+    if (every < 1) return fail(MSST_ERR_BADARG, "msst_profile_sample");
+    g_prof_every.store(every);
+    for (int i = 0; i < K_COUNT; ++i) g_prof_seen[i].store(0u);
+    return 0;
+}
 
 int msst_profile_kernels(void) { return K_COUNT; }
 
@@ -222,7 +238,7 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
 int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x1, int mode, int B, int S,
                    int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed, int layer,
                    void* xn_out, int* xn_written, void* stream) {
-    if (!w || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd");
+    if (!bw_ok(w) || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd (null argument, or MsstBlockWeights of another header revision)");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (sequence length > 64)");
     const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
     prec &= 0xff;
@@ -295,7 +311,8 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
                           const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                           int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
                           uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int chain, int first, hipStream_t st) {
-    if (!w || !g || grid_rows < 1 || nchunk < 1) return fail(MSST_ERR_BADARG, "msst_block_bwd");
+    if (!bw_ok(w) || (w_prev && !bw_ok(w_prev)) || !g || grid_rows < 1 || nchunk < 1)
+        return fail(MSST_ERR_BADARG, "msst_block_bwd (null argument, or MsstBlockWeights of another header revision)");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
     const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
     prec &= 0xff;

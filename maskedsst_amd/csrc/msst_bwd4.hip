@@ -642,7 +642,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     if (!grp) {
 #pragma unroll
         for (int i = 0; i < MSST_B4_LAG; ++i) lds_barrier();   // head A: the barriers head B is behind
-    } else {
+    } else if ((int)blockIdx.x < a.ntiles) {   // (a workgroup without a tile never filled seqout: nothing to copy out)
         copy_out();
     }
 
@@ -666,7 +666,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st) {
     static std::atomic<bool> attr_set{false};
     if (a.tm.L > 64 || a.tm.L < 1 || (a.H & 1)) return MSST_ERR_UNSUPPORTED;
-    if (!a.xn || !a.dab || !a.w.wqkv32 || !a.w.woutT32 || !a.w.wqkvT32) return MSST_ERR_BADARG;
+    if (!a.xn || !a.dab || !a.w.wqkv32 || !a.w.woutT32 || !a.w.wqkvT32 || nchunk < 1 || nchunk > a.ntiles) return MSST_ERR_BADARG;
     if (a.ntok * 192 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit row offsets of the copy-out descriptor
     typedef void (*kern_t)(AttnBwdArgs);
     const kern_t kerns[2] = {&block_bwd_attn_r4_kernel<false>, &block_bwd_attn_r4_kernel<true>};

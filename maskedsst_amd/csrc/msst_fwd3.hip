@@ -1,0 +1,701 @@
+// bf16 forward of one transformer block, ROLE-SPLIT (round 4; reference vit_spatial_spectral.py:22-104: PreNorm + Attention +
+// residual, PreNorm + FeedForward + residual; a7-a10 of SURVEY.md section 8).  Same math, same dropout streams and the same
+// HBM interface as block_fwd_hw_kernel (msst_fwd2.hip); what changes is WHEN the phases of a tile run.
+//
+// In msst_fwd2.hip all eight waves of the workgroup walk the same phase sequence in lockstep: the head phase (q / k / v
+// projections + attention: ~11 k of the 26 k-cycle tile, where both waves of a SIMD fight for its VALU) and then five row-local
+// phases separated by barriers (LN1, out-projection, LN2, two MLP GEMMs: ~13 k cycles for 0.8 k cycles of MFMA work -- LDS /
+// L2 round trips and barriers nobody fills).  Here the two kinds of work are ROLES, one wave of each per SIMD:
+//   * waves 0-3 ("A"): the head phase only, for TWO heads per tile (head w in round 0, head w + 4 in round 1): the whole
+//     attention of a head in registers exactly as in msst_fwd2.hip; O rows go to the round's half of the bf16 O tile.
+//   * waves 4-7 ("R"): everything row-local, software-pipelined over three tiles: while the A waves compute tile k they run
+//     LN1 of tile k + 1, the first K half of the out-projection of tile k (as soon as round 0's O rows are complete) and the
+//     second K half + bias / dropout / residual / LN2 / MLP of tile k - 1.  R wave (mh, rh) owns rows 32 rh .. + 31 x features
+//     48 mh .. + 47 of the out-projection (each Wout fragment serves two row tiles, the full K runs on one wave: no K-half
+//     exchange), the same rows x hidden half mh of the first MLP GEMM and x output half mh of the second.
+// Four barriers per tile (the middle and the end of each round) are the only synchronisation: every cross-wave hand-over of
+// the R pipeline (LN2 statistics of the two feature halves, LN2 rows, GELU rows) is placed across one of them.
+//
+//   interval   A waves (tile k)                 R waves
+//   q0         round 0: projections, j = 0, 1   out-projection K half 1 of tile k-1 (O of round 1), bias / dropout / +x -> x1,
+//                                               partial LN2 statistics
+//   q1         round 0: j = 2, 3                LN2 of tile k-1 -> XN2; Wout fragments of K half 0 requested
+//   q2         round 1: projections, j = 0, 1   out-projection K half 0 of tile k (O of round 0); MLP GEMM 1 + GELU of tile k-1
+//   q3         round 1: j = 2, 3                MLP GEMM 2 of tile k-1 -> y; LN1 of tile k+1 -> XN[(k+1) & 1]
+#include <atomic>
+#include "msst_dev.h"
+#include "msst_kernels.h"
+#include <type_traits>
+
+#ifndef MSST_F3_RING
+#define MSST_F3_RING 4
+#endif
+#ifndef MSST_F3_RPRIO
+#define MSST_F3_RPRIO 1
+#endif
+#ifndef MSST_F3_KM
+#define MSST_F3_KM 0   // 1: the R waves hash the keep masks of the attention-probability dropout (64-bit row masks in LDS), the A waves only
+                       // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
+                       // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
+#endif
+#ifndef MSST_F3_EXP
+#define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic
+#endif
+
+#ifdef MSST_STAMPS
+#define F3_STAMP(i) do { if (stamp_on) a.stamps[16 * wv + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define F3_STAMP(i) do { } while (0)
+#endif
+
+namespace msst {
+
+namespace {
+
+typedef PBF16 P;
+typedef bf16_t elem;
+typedef s16x8 frag;
+
+__device__ __forceinline__ float oct_sum3(float v) {   // (unused by the 4-threads-per-row LN1 below; kept for 8-thread variants)
+    v = quad_sum(v);
+    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
+}
+
+struct Fwd3Smem {
+    static constexpr int LDX = 96 + 16;    // row stride = 2 mod 4 sixteen-byte slots: conflict-free b128 fragment reads
+    static constexpr int LDH = 64 + 8;
+    static constexpr int LDO = 256 + 16;   // 34 slots = 2 mod 4
+    elem xn[2][64][LDX];                   // LN1(x) of the tile of walk step k (by parity)
+    elem ob[2][64][LDO];                   // attention output of round r: [row][local head * 64 + channel]
+    elem xn2[64][LDX];                     // LN2(x1)
+    elem hb[64][LDH];                      // GELU(W1 .) of the MLP
+    float2 st[4][32];                      // LN2 partial statistics (mean, M2 over 48 features): [R wave][row of its 32]
+    unsigned rowmap[64];                   // tile row -> (sequence slot << 16 | position), 0xffff = padding row: tile invariant
+    unsigned long long vm[64];             // key-validity mask of a query row: bit k set <=> key row k belongs to the query's sequence (tile invariant)
+    unsigned long long km[MSST_F3_KM ? 2 : 1][MSST_F3_KM ? 8 : 1][64];   // (MSST_F3_KM) keep mask of the attention-probability dropout (site 1): [walk-step parity][head][query row], bit = key
+    int seqb[4][64];                       // token of position 0 of every sequence slot, tiles of walk steps k - 1 .. k + 1 (by k & 3)
+    float lnp[640];                        // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1
+    char wmlp[24 * 1024];                  // [w1: 12 frags | w2: 12 frags]
+};
+
+__device__ __forceinline__ int sopaque3(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+
+__device__ __forceinline__ frag pack2f(f32x4 lo, f32x4 hi) {
+    const s16x4 a = f2bf4(lo), b = f2bf4(hi);
+    frag r;
+    r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+    r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+    return r;
+}
+
+// fragment of 16 GATHERED rows of a fragment-packed [R][K] weight (see msst_fwd2.hip)
+__device__ __forceinline__ frag ld_w_gather3(const elem* w, int K, int row32, int k0, int voff) {
+    const int f = (row32 >> 4) * (K >> 5) + (k0 >> 5);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(w), 0, 0x7fffffff, 0x00020000);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, f * 1024, 0);
+    return __builtin_bit_cast(frag, v);
+}
+
+// weight-fragment pair number pi of head h: 0..5 q, 6..11 k, 12..17 gathered v (see msst_fwd2.hip)
+__device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* wqkv, int H, int h, const int (&voff)[2]) {
+    if (pi < 12) {
+        const int st = pi / 3, ks = pi % 3;
+        const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
+        out[0] = P::ld_w(wqkv, 96, r0, ks * 32);
+        out[1] = P::ld_w(wqkv, 96, r0 + 16, ks * 32);
+    } else {
+        const int mm = (pi - 12) / 3, ks = (pi - 12) % 3;
+        const int r32 = (2 * H + h) * 64 + mm * 32;
+        out[0] = ld_w_gather3(wqkv, 96, r32, ks * 32, voff[0]);
+        out[1] = ld_w_gather3(wqkv, 96, r32, ks * 32, voff[1]);
+    }
+}
+
+}  // namespace
+
+template <bool DROP>
+__global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
+    typedef Fwd3Smem SM;
+    constexpr int LDX = SM::LDX, LDH = SM::LDH, LDO = SM::LDO;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    SM& sm = *reinterpret_cast<SM*>(smem_raw);
+
+    const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
+    const int H = a.H, inner = H * 64;
+    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
+    const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
+    const TileMap tm = a.tm;
+    const int L = tm.L;
+    const int G = (int)gridDim.x;
+    const int nmine = ((int)blockIdx.x < a.ntiles) ? (a.ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
+    auto tile_at = [&](int k) { return (int)blockIdx.x + k * G; };
+
+    // ---- common prologue: small parameter vectors, MLP weights, token tables ----
+    float* lnp = sm.lnp;
+    if (tid < 96) {
+        lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; lnp[192 + tid] = a.w.bo[tid];
+        lnp[288 + tid] = a.w.ln2_g[tid]; lnp[384 + tid] = a.w.ln2_b[tid]; lnp[480 + tid] = a.w.b2[tid];
+        if (tid < 64) lnp[576 + tid] = a.w.b1[tid];
+    }
+#pragma unroll
+    for (int i3 = 0; i3 < 3; ++i3) {
+        const int f = wv * 3 + i3;
+        dma_frag(f < 12 ? reinterpret_cast<const char*>(a.w.w1) + f * 1024 : reinterpret_cast<const char*>(a.w.w2) + (f - 12) * 1024,
+                 sm.wmlp + f * 1024);
+    }
+    wait_vm0();
+    if (tid < 64) {
+        const int sq = tid / L, ps = tid - sq * L;
+        sm.rowmap[tid] = ((unsigned)(sq >= tm.TS ? 0xffff : sq) << 16) | (unsigned)ps;
+    }
+    // sequence bases of walk step k (tile tile_at(k)) -> seqb[k & 3]; steps outside the walk: all -1 (padding)
+    auto fill_seq = [&](int k, int t64) {
+        const int tile_ = tile_at(k);
+        const int q = tile_ * tm.TS + t64;
+        int base = -1;
+        if (k >= 0 && k < nmine && t64 < tm.TS && q < tm.nseq) {
+            if (tm.mode == 0) base = q * tm.N;
+            else { const int b = tm.nshift >= 0 ? (q >> tm.nshift) : q / tm.N; base = b * tm.T + (q - b * tm.N); }
+        }
+        sm.seqb[k & 3][t64] = base;
+    };
+    if (tid < 64) { fill_seq(0, tid); fill_seq(1, tid); }
+    if (tid >= 64 && tid < 128) {
+        const int r = tid - 64, sq = r / L;
+        unsigned long long m = ~0ull;   // (padding rows see every key: finite garbage that is never stored, not NaN)
+        if (sq < tm.TS && L < 64) m = ((1ull << L) - 1ull) << (sq * L);
+        sm.vm[r] = m;
+    }
+    __syncthreads();
+    auto tok_of = [&](int k, int r) -> long {
+        const unsigned sp = sm.rowmap[r];
+        const int base = sm.seqb[k & 3][min((int)(sp >> 16), 63)];
+        return ((sp >> 16) == 0xffffu || base < 0) ? -1 : (long)(base + (int)(sp & 0xffffu) * (tm.mode == 0 ? 1 : tm.N));
+    };
+
+    if (wv < 4) {
+        // =====================================================================================================
+        // A role: heads wv (round 0) and wv + 4 (round 1) of every tile, all in registers (msst_fwd2.hip's head phase)
+        // =====================================================================================================
+        int voff[2];
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi) {
+            const int rs = 8 * (c >> 2) + (c & 3) + 4 * hi;   // 0..31
+            voff[hi] = ((rs >> 4) * 3) * 1024 + (g * 16 + (rs & 15)) * 16;   // K = 96 -> 3 fragments per 16 rows
+        }
+        int qlo[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) qlo[j] = ((j * 16 + c) / L) * L;
+        constexpr int NR = MSST_F3_RING;
+        static_assert(NR >= 2 && NR <= 9, "ring depth");
+        frag ring[NR][2];
+        // pair to request into slot pi % NR once pair pi is consumed: NR ahead in the 18-pair stream of a head, wrapping to the
+        // first pairs of the NEXT head of this wave (the other round's)
+        // (pair p of a head always lives in slot p % NR: for pi >= 18 - NR the freed slots pi % NR run through 0 .. NR - 1 exactly once)
+        auto next_pair = [](int pi) { return pi + NR < 18 ? pi + NR : pi % NR; };
+#pragma unroll
+        for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wqkv, H, wv, voff);
+
+        __syncthreads();   // (P1) LN1 of the first tile is in XN[0]
+        for (int k = 0; k < nmine; ++k) {
+            const int tile = tile_at(k);
+#ifdef MSST_STAMPS
+            const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nmine / 2;
+#endif
+            F3_STAMP(0);
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int h = wv + 4 * rd;                  // this round's head
+                const int hn = wv + 4 * (1 - rd);           // the head whose first pairs follow in the weight stream
+                frag qB[4][2], kA[4][2], vA[4][2];
+                {
+                    frag xf[4][3];   // LN1(x) as operand fragments: [16-row tile][k-step]
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int ks = 0; ks < 3; ++ks) xf[t][ks] = P::ld_kc(&sm.xn[k & 1][t * 16][ks * 32], LDX);
+#pragma unroll
+                    for (int st = 0; st < 6; ++st) {
+                        if (st < 4) {
+                            const int m = st & 1;
+                            f32x4 ca[4], cb[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { ca[t] = zero4(); cb[t] = zero4(); }
+#pragma unroll
+                            for (int ks = 0; ks < 3; ++ks) {
+                                const int pi = 3 * st + ks;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
+                                    cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                if (st < 2) qB[t][m] = pack2f(ca[t], cb[t]); else kA[t][m] = pack2f(ca[t], cb[t]);
+                            }
+                        } else {
+                            const int mm = st - 4;
+                            f32x4 cl[4], ch[4];
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) { cl[t] = zero4(); ch[t] = zero4(); }
+#pragma unroll
+                            for (int ks = 0; ks < 3; ++ks) {
+                                const int pi = 3 * st + ks;
+#pragma unroll
+                                for (int t = 0; t < 4; ++t) {
+                                    cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
+                                    ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                            vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
+                            vA[2 * mm + 1][0] = pack2f(ch[0], ch[1]); vA[2 * mm + 1][1] = pack2f(ch[2], ch[3]);
+                        }
+                    }
+                }
+                F3_STAMP(1 + 5 * rd);   // projections done
+                // ---- attention of head h, TWO query tiles at a time, phase by phase: the A wave is alone on its SIMD's VALU most of
+                // the time, so the latency of its own dependent chain (S MFMAs -> max -> exp -> sum -> 1 / x -> dropout -> P V MFMAs ->
+                // pack) is what it waits for; two independent query tiles in flight fill those slots.  O rows go to the round's
+                // half of the O tile. ----
+                const float cs = a.scale * 1.44269504088896340736f;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    f32x4 s[2][4];
+                    f32x4 o[2][4];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
+                            s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);
+                        }
+                    if (!(MSST_F3_EXP & 4)) {
+                        // bit position of key 16 t + 4 g + r inside its 32-bit half of a 64-bit row mask: 16 (t & 1) + 4 g + r
+                        int lq = threadIdx.x & 63;
+                        asm volatile("" : "+v"(lq));
+                        const int cq = lq & 15, sh0 = 4 * (lq >> 4);
+                        float mx[2] = {-INFINITY, -INFINITY};
+                        if (L == 64) {
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) mx[u] = fmaxf(mx[u], s[u][t][r]);
+                        } else {
+                            // several short sequences per tile: keys outside the query's own sequence are masked.  The validity of a
+                            // key is one bit of the query row's 64-bit mask (LDS, tile invariant): a sign-extending 1-bit field extract
+                            // gives 0 / ~0 and v_bfi selects score or -inf -- two full-rate instructions per score and no lane masks
+                            // (as compares against [lo, hi) the 64 lane masks of a wave were hoisted into SGPR pairs and spilled)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                const unsigned long long vmq = sm.vm[(2 * jp + u) * 16 + cq];
+                                const int vlo = (int)(unsigned)vmq, vhi = (int)(unsigned)(vmq >> 32);
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) {
+                                        const int m = __builtin_amdgcn_sbfe(t < 2 ? vlo : vhi, 16 * (t & 1) + sh0 + r, 1);   // 0 or -1
+                                        const float v = __int_as_float((__float_as_int(s[u][t][r]) & m) | (~m & (int)0xff800000));
+                                        s[u][t][r] = v;
+                                        mx[u] = fmaxf(mx[u], v);
+                                    }
+                            }
+                        }
+                        float mc[2], sum[2] = {0.f, 0.f}, inv[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) mc[u] = colgroup_max(mx[u]) * cs;
+                        // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e: one FMA + one v_exp per element
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], cs, -mc[u])); s[u][t][r] = e; sum[u] += e; }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(colgroup_sum(sum[u]));   // the dropout scale rides on the normalisation
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            // site 1: the keep bits of this query row come from the R waves (they hash while this wave computes: 48 quarter-rate
+                            // multiplies per lane and head less on the critical wave); same masks as drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g)
+                            int klo = -1, khi = -1;
+                            if (DROP && MSST_F3_KM) {
+                                const unsigned long long kmq = sm.km[k & 1][h][(2 * jp + u) * 16 + cq];
+                                klo = (int)(unsigned)kmq; khi = (int)(unsigned)(kmq >> 32);
+                            }
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                s[u][t] = s[u][t] * inv[u];
+                                if (DROP && MSST_F3_KM) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r)
+                                        s[u][t][r] = __int_as_float(__float_as_int(s[u][t][r]) & __builtin_amdgcn_sbfe(t < 2 ? klo : khi, 16 * (t & 1) + sh0 + r, 1));
+                                } else if (DROP) {
+                                    s[u][t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + (2 * jp + u) * 16 + cq) * 16 + t * 4 + (sh0 >> 2)), s[u][t]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const frag p0 = pack2f(s[u][0], s[u][1]), p1 = pack2f(s[u][2], s[u][3]);
+#pragma unroll
+                        for (int dd = 0; dd < 4; ++dd) {
+                            o[u][dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
+                            o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
+                        }
+                    }
+                    // pack2(o[2u'], o[2u' + 1]) holds, in lane (c, g), the natural channels 32 u' + 8 g .. + 7 of query row 16 j + c
+                    int l4 = threadIdx.x & 63;
+                    asm volatile("" : "+v"(l4));
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        elem* orow = &sm.ob[rd][(2 * jp + u) * 16 + (l4 & 15)][wv * 64 + 8 * (l4 >> 4)];
+                        *reinterpret_cast<frag*>(orow) = pack2f(o[u][0], o[u][1]);
+                        *reinterpret_cast<frag*>(orow + 32) = pack2f(o[u][2], o[u][3]);
+                    }
+                    // q0 / q2 (middle of the round), q1 / q3 (its end: the round's O rows are complete)
+                    F3_STAMP(2 + 5 * rd + 2 * jp);
+                    lds_barrier();
+                    F3_STAMP(3 + 5 * rd + 2 * jp);
+                }
+            }
+        }
+        // the R waves finish the last tile: four more intervals
+#pragma unroll
+        for (int i = 0; i < 4; ++i) lds_barrier();
+        return;
+    }
+
+    // =========================================================================================================
+    // R role: row-local work, pipelined over tiles k - 1 (second half of the out-projection .. MLP), k (first half of the
+    // out-projection) and k + 1 (LN1)
+    // =========================================================================================================
+    const int rw = wv - 4, mh = rw & 1, rh = rw >> 1;
+    const int rt = tid - 256;                   // 0..255: LN1 thread <-> (row rt / 4, 24 features 16 (i / 4) + 4 (rt % 4) + i % 4)
+    const elem* w1l = reinterpret_cast<const elem*>(sm.wmlp);
+    (void)w1l;
+
+    // ---- LN1 of walk step k: x rows -> XN[k & 1] (+ the bf16 rows to HBM for the attention backward) ----
+    f32x4 xv[6];   // this thread's 24 row values of the tile LN1 processes next (requested one interval ahead)
+    auto request_ln1 = [&](int k) {
+        int rt = (int)threadIdx.x - 256;
+        asm volatile("" : "+v"(rt));
+        const long tok = tok_of(k, rt >> 2);
+        const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 4 * (rt & 3);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xrow + 16 * i);
+    };
+    auto ln1 = [&](int k) {
+        int rt = (int)threadIdx.x - 256;
+        asm volatile("" : "+v"(rt));
+        const int lr = rt >> 2, part = rt & 3;
+        const long tok = tok_of(k, lr);
+        float v[24];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
+        if (tok < 0) {   // padding row: the request read a clamped address, normalise zeros
+#pragma unroll
+            for (int i = 0; i < 24; ++i) v[i] = 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) s += v[i];
+        const float mean = quad_sum(s) * (1.f / 96.f);
+        float vs = 0.f;
+#pragma unroll
+        for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
+        const float rstd = rsqrtf(quad_sum(vs) * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int f0 = 16 * i + 4 * part;
+            f32x4 n4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[f0 + e] + lnp[96 + f0 + e];
+            const s16x4 nb = f2bf4(n4);
+            *reinterpret_cast<s16x4*>(&sm.xn[k & 1][lr][f0]) = nb;
+            if (a.xn_out && tok >= 0) *reinterpret_cast<s16x4*>(reinterpret_cast<elem*>(a.xn_out) + tok * 96 + f0) = nb;
+        }
+    };
+
+    // out-projection state of the tile in flight: rows 32 rh + 16 jj + c, features 48 mh + 16 i + 4 g .. + 3
+    f32x4 acc[2][3];
+    f32x4 x1r[2][3];   // x1 of the owned rows / features of tile k - 1: in registers until the end of its MLP
+    f32x4 xr[2][3];    // residual x values of the tile whose out-projection completes next
+    float mean_w[2], m2_w[2];
+    // per-thread indices are re-derived from a laundered lane id inside every stage: derived once, the compiler hoists two dozen
+    // lane-dependent addresses out of the walk, keeps them live across all stages and spills them (each reload carries a vmcnt(0)
+    // that also waits for the weight fragments in flight)
+#define F3_LANE() int l3 = threadIdx.x & 63; asm volatile("" : "+v"(l3)); const int g3 = l3 >> 4, c3 = l3 & 15; (void)g3; (void)c3
+
+    auto request_xr = [&](int k) {
+        F3_LANE();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
+            const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 48 * mh + 4 * g3;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) xr[jj][i] = *reinterpret_cast<const f32x4*>(xrow + 16 * i);
+        }
+    };
+    // one K half (round rd's O rows) of the out-projection: C[i = feature][j = row].  Its 24 weight fragments are requested at
+    // the END of the interval before (a light one: LN2, or MLP GEMM 2 + LN1 with their registers already dead), so that the
+    // barrier wait hides the L2 round trip: requested inside the phase through a ring of four k-steps, every refill sat out a
+    // whole L2 latency (6 MFMAs of cover per k-step): 6.6 k cycles for 48 MFMAs.
+    frag fw[8][3];
+    auto request_fw = [&](int rd) {
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque3(mh) + i) * 16, (8 * rd + s8) * 32);
+    };
+    auto outproj = [&](int rd) {
+        if (MSST_F3_EXP & 2) return;
+        F3_LANE();
+        frag fo[4][2];   // O row fragments of a k-step, requested three k-steps ahead
+        swpipe<8, 3>(
+            [&](int s8) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) fo[s8 % 4][jj] = P::ld_kc(&sm.ob[rd][(2 * rh + jj) * 16][s8 * 32], LDO);
+            },
+            [&](int s8) {
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) acc[jj][i] = P::mma(fw[s8][i], fo[s8 % 4][jj], acc[jj][i]);
+            });
+    };
+    // bias, dropout, residual -> x1 (registers + HBM); partial LN2 statistics of the 48 owned features -> ST
+    auto epilogue1 = [&](int k) {
+        F3_LANE();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int m0 = (3 * mh + i) * 16 + 4 * g3;
+                f32x4 o4 = acc[jj][i];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o4[r] += lnp[192 + m0 + r];
+                if (DROP && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                o4 = o4 + xr[jj][i];
+                x1r[jj][i] = o4;
+                s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
+                if (a.x1 && tok >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+            }
+            const float mw = colgroup_sum(s1) * (1.f / 48.f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float d = x1r[jj][i][r] - mw; m2 += d * d; }
+            m2 = colgroup_sum(m2);
+            mean_w[jj] = mw; m2_w[jj] = m2;
+            if (g3 == 0) sm.st[rw][16 * jj + c3] = make_float2(mw, m2);
+        }
+    };
+    // LN2 of the owned rows (statistics combined with the other feature half) -> XN2
+    auto ln2 = [&]() {
+        F3_LANE();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const float2 other = sm.st[rw ^ 1][16 * jj + c3];
+            const float mean = 0.5f * (mean_w[jj] + other.x);
+            const float dm = mean_w[jj] - other.x;
+            const float var = (m2_w[jj] + other.y + dm * dm * 24.f) * (1.f / 96.f);   // Chan's pairwise combination, n = 48 + 48
+            const float rstd = rsqrtf(var + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int m0 = (3 * mh + i) * 16 + 4 * g3;
+                f32x4 n4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) n4[r] = (x1r[jj][i][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
+                *reinterpret_cast<s16x4*>(&sm.xn2[32 * rh + 16 * jj + c3][m0]) = f2bf4(n4);
+            }
+        }
+    };
+    // MLP GEMM 1 + GELU: rows 32 rh .., hidden units 32 mh .. + 31 -> HB
+    auto mlp1 = [&](int k) {
+        if (MSST_F3_EXP & 1) return;
+        F3_LANE();
+        f32x4 hh[2][2];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) { hh[jj][0] = zero4(); hh[jj][1] = zero4(); }
+        frag xb[2][3], w1f[2][3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) xb[jj][ks] = P::ld_kc(&sm.xn2[(2 * rh + jj) * 16][ks * 32], LDX);
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) w1f[jn][ks] = *reinterpret_cast<const frag*>(sm.wmlp + ((2 * mh + jn) * 3 + ks) * 1024 + l3 * 16);
+        }
+        MSST_SCHED_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) hh[jj][jn] = P::mma(w1f[jn][ks], xb[jj][ks], hh[jj][jn]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int n0 = (2 * mh + jn) * 16 + 4 * g3;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hh[jj][jn][r] = gelu_fast(hh[jj][jn][r] + lnp[576 + n0 + r]);
+                if (DROP && tok >= 0) hh[jj][jn] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jj][jn]);
+                P::st_nat(&sm.hb[(2 * rh + jj) * 16][(2 * mh + jn) * 16], LDH, hh[jj][jn]);
+            }
+        }
+    };
+    // MLP GEMM 2 + bias, dropout, residual -> y
+    auto mlp2 = [&](int k) {
+        if (MSST_F3_EXP & 1) return;
+        F3_LANE();
+        f32x4 yy[2][3];
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int jm = 0; jm < 3; ++jm) yy[jj][jm] = zero4();
+        frag hbf[2][2], w2f[3][2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) hbf[jj][ks] = P::ld_kc(&sm.hb[(2 * rh + jj) * 16][ks * 32], LDH);
+#pragma unroll
+            for (int jm = 0; jm < 3; ++jm) w2f[jm][ks] = *reinterpret_cast<const frag*>(sm.wmlp + (12 + (3 * mh + jm) * 2 + ks) * 1024 + l3 * 16);
+        }
+        MSST_SCHED_FENCE();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                for (int jm = 0; jm < 3; ++jm) yy[jj][jm] = P::mma(w2f[jm][ks], hbf[jj][ks], yy[jj][jm]);
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
+            if (tok >= 0) {
+#pragma unroll
+                for (int jm = 0; jm < 3; ++jm) {
+                    const int m0 = (3 * mh + jm) * 16 + 4 * g3;
+                    f32x4 o4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o4[r] = yy[jj][jm][r] + lnp[480 + m0 + r];
+                    if (DROP) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                    o4 = o4 + x1r[jj][jm];
+                    *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+                }
+            }
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) acc[jj][i] = zero4();
+    };
+
+    // keep masks of the attention-probability dropout of walk step k -> km[k & 1]: R lane rt hashes the 16 element groups of
+    // (head, query row) = (2 part + rt / 128 ..., rt % 64): two rows per lane and tile, one per call (part = 0, 1)
+    auto keep_masks = [&](int k, int part) {
+        if (!DROP || !MSST_F3_KM || k >= nmine) return;
+        int rt = (int)threadIdx.x - 256;
+        asm volatile("" : "+v"(rt));
+        const int hq = part * 256 + rt, hh = hq >> 6, q = hq & 63;   // head 0..7, query row 0..63
+        const unsigned base = (unsigned)(((tile_at(k) * H + hh) * 64 + q) * 16);
+        const unsigned t16 = a.drop.thr << 16;
+        unsigned w[2] = {0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                unsigned ha, hb;
+                drop_bits(a.drop, 1, base + (unsigned)(t * 4 + gg), ha, hb);
+                const unsigned bits = (unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
+                                      ((unsigned)(hb >= t16) << 3);
+                w[t >> 1] |= bits << (16 * (t & 1) + 4 * gg);
+            }
+        sm.km[k & 1][hh][q] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
+    };
+    // ---- prologue: LN1 of the first tile ----
+    request_ln1(0);
+    ln1(0);
+    keep_masks(0, 0); keep_masks(0, 1);
+    zero_acc();
+    request_fw(0);   // (a definition on every path: step 0 has no out-projection in q0)
+    __syncthreads();   // (P1)
+    if (MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);   // the R waves are the later-dispatched half: they lose every VALU arbitration to the A wave of their SIMD otherwise
+    // walk steps 0 .. nmine: step k runs q0 / q1 for tile k - 1 (k >= 1), q2 for tile k (k < nmine) and tile k - 1, q3 for tiles k - 1 and k + 1
+    for (int k = 0; k <= nmine; ++k) {
+        const bool have_prev = k >= 1, have_cur = k < nmine;
+#ifdef MSST_STAMPS
+        const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nmine / 2;
+#endif
+        F3_STAMP(0);
+        // ---------------- q0 ----------------
+        if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); }
+        F3_STAMP(2);
+        lds_barrier();
+        F3_STAMP(3);
+        // ---------------- q1 ----------------
+        if (have_prev) ln2();
+        keep_masks(k + 1, 0);
+        if (rt < 64) fill_seq(k + 2, rt);   // (first read in q1 of the next step: LN1 request of step k + 2)
+        if (have_cur) zero_acc();
+        request_fw(0);
+        F3_STAMP(4);
+        lds_barrier();
+        F3_STAMP(5);
+        // ---------------- q2 ----------------
+        if (have_cur) outproj(0);
+        F3_STAMP(6);
+        if (have_prev) mlp1(k - 1);
+        if (k + 1 < nmine) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
+        F3_STAMP(7);
+        lds_barrier();
+        F3_STAMP(8);
+        // ---------------- q3 ----------------
+        if (have_prev) mlp2(k - 1);
+        keep_masks(k + 1, 1);
+        F3_STAMP(9);
+        if (k + 1 < nmine) ln1(k + 1);
+        request_fw(1);
+        F3_STAMP(10);
+        lds_barrier();
+        F3_STAMP(11);
+    }
+}
+
+int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st) {
+    static std::atomic<bool> attr_set{false};
+    const size_t smem = sizeof(Fwd3Smem);
+    if (a.H != 8) return MSST_ERR_UNSUPPORTED;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_rs_kernel<false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_rs_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    ProfScope ps(K_BLOCK_FWD, st);
+    if (a.drop.thr) hipLaunchKernelGGL(block_fwd_rs_kernel<true>, dim3(grid), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL(block_fwd_rs_kernel<false>, dim3(grid), dim3(512), smem, st, a);
+    return (int)hipGetLastError();
+}
+
+}  // namespace msst

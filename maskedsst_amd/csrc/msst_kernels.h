@@ -196,7 +196,8 @@ int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, flo
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                  float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st);   // msst_opt.hip (occupancy probe)
-int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd2.hip (bf16, 8 heads)
+int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd2.hip (bf16, 8 heads; head per wave, lockstep phases)
+int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd3.hip (bf16, 8 heads; role split: the default)
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
 bool block_fwd_writes_xn(const BlockArgs& a, int prec);   // does the kernel launch_block_fwd selects honour a.xn_out?
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st);

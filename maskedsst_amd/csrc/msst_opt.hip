@@ -3,6 +3,7 @@
 //   g' = clamp(g * gscale, -clamp, clamp)      (pretrain.py:71-73 value clamp; gscale = 1/world for DP mean)
 //   p  = p * (1 - lr*wd);  m = b1 m + (1-b1) g';  v = b2 v + (1-b2) g'^2
 //   p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include <atomic>
 #include "msst_dev.h"
 #include "msst_kernels.h"
 #include <math.h>
@@ -60,9 +61,10 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
     return (int)hipGetLastError();
 }
 
-// CU-occupancy probe for the data-parallel overlap: `nblocks` workgroups that do nothing but hold their CU
-// slot (a full register budget, so that nothing else fits beside them -- like a communication kernel's channel
-// workgroups) until `us` microseconds of the constant-rate device clock have passed.  bench.py --cu-thief runs it on a
+// CU-occupancy probe for the data-parallel overlap: `nblocks` workgroups that do nothing but hold a CU each
+// -- they declare all 160 KB of its LDS, so no workgroup that uses LDS (every MFMA kernel here) fits beside one, like a CU
+// lost to a communication kernel's channel workgroup -- until `us` microseconds of the constant-rate device clock have passed.
+// (__launch_bounds__ only CAPS the register allocation; the handful of registers this kernel uses excludes nobody.)  bench.py --cu-thief runs it on a
 // side stream under the backward to measure what the static grids of the MFMA kernels lose to RCCL's channels.
 __global__ __launch_bounds__(256, 2) void cu_thief_kernel(unsigned long long ticks, unsigned* sink) {
     const unsigned long long t0 = wall_clock64();
@@ -76,14 +78,14 @@ __global__ __launch_bounds__(256, 2) void cu_thief_kernel(unsigned long long tic
 
 int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st) {
     if (nblocks < 1 || us < 1) return 0;
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_thief_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&cu_thief_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
     // wall_clock64 ticks at 100 MHz on gfx9
-    hipLaunchKernelGGL(cu_thief_kernel, dim3(nblocks), dim3(256), 64 * 1024, st, (unsigned long long)us * 100ull, sink);
+    hipLaunchKernelGGL(cu_thief_kernel, dim3(nblocks), dim3(256), 160 * 1024, st, (unsigned long long)us * 100ull, sink);
     return (int)hipGetLastError();
 }
 

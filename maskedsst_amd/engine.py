@@ -52,8 +52,11 @@ class Engine:
         self.fp = FlatParams(encoder, mim)
         self.prec = _prec_of(getattr(encoder, "precision", None))
         self.max_grid = int(os.environ.get("MSST_MAX_GRID", "0"))
-        self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "256"))      # persistent grid of the row-wise bwd kernels
-        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "64"))  # x heads workgroups in the attention bwd
+        # persistent grids of the backward: one row-wise workgroup per CU; tile chunks of the attention backward so that its
+        # (chunks x heads or head pairs) grid fills every CU slot exactly once (64 x 4 two-head workgroups on 256 CUs)
+        self.grid_rows = int(os.environ.get("MSST_BWD_GRID", "0")) or (self._cu_count() if torch.cuda.is_available() else 256)
+        self.attn_chunks = int(os.environ.get("MSST_ATTN_CHUNKS", "0")) or \
+            (self.default_attn_chunks() if torch.cuda.is_available() else 64)
         self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "64"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self._wbuf = None
@@ -74,14 +77,31 @@ class Engine:
     def P(self):
         return self.enc.pixels_per_patch
 
-    def reserve_cus(self, n, total=256):
-        """Leave ``n`` of the chip's CUs free of backward workgroups (data parallel: RCCL's channels).  The attention
-        backward runs heads x chunks workgroups at two per CU, the row-wise kernels one (two for the MLP half) per grid
-        row; explicit MSST_ATTN_CHUNKS / MSST_BWD_GRID settings win."""
-        n = max(0, min(int(n), total - 8))
+    def _cu_count(self):
+        try:
+            return int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+        except Exception:
+            return 256
+
+    def _attn_wgs_per_chunk_and_cu(self):
+        """(workgroups per tile chunk, workgroups per CU) of the bf16 attention backward this engine selects: the two-head
+        kernel (even head count) launches H/2 workgroups of 512 threads per chunk, one per CU (156 KB of LDS); the one-head
+        kernels H workgroups of 256 threads, two per CU."""
         H = max(1, int(self.enc.heads))
+        return (H // 2, 1) if H % 2 == 0 else (H, 2)
+
+    def default_attn_chunks(self, free_cus=0):
+        per_chunk, per_cu = self._attn_wgs_per_chunk_and_cu()
+        return max(1, (per_cu * max(8, self._cu_count() - free_cus)) // per_chunk)
+
+    def reserve_cus(self, n):
+        """Leave ``n`` of the chip's CUs free of backward workgroups (data parallel: RCCL's channels).  The persistent grids are
+        derived from the device's CU count and from how many workgroups of the selected attention backward fit a CU;
+        explicit MSST_ATTN_CHUNKS / MSST_BWD_GRID settings win."""
+        total = self._cu_count()
+        n = max(0, min(int(n), total - 8))
         if "MSST_ATTN_CHUNKS" not in os.environ:
-            self.attn_chunks = max(1, (2 * (total - n)) // H)
+            self.attn_chunks = self.default_attn_chunks(n)
         if "MSST_BWD_GRID" not in os.environ:
             self.grid_rows = total - n
 
@@ -117,7 +137,8 @@ class Engine:
         esz = 4 if self.prec == PREC_F32 else 2
         mats = [("wqkv", 3 * inner, D), ("wout", D, inner), ("w1", MLP, D), ("w2", D, MLP)]
         # bf16: three more copies in the 32-row x 16-k fragment packing of the round-3 attention backward (32x32x16 MFMAs)
-        mats32 = [("wqkv", 3 * inner, D, 0, "wqkv32", 1), ("wout", D, inner, 1, "woutT32", 1), ("wqkv", 3 * inner, D, 1, "wqkvT32", 2)] \
+        # (name, rows, cols, transpose, field, scale_rows): pack = 1; wqkvT32 carries dim_head^-0.5 in its q and k blocks
+        mats32 = [("wqkv", 3 * inner, D, 0, "wqkv32", 0), ("wout", D, inner, 1, "woutT32", 0), ("wqkv", 3 * inner, D, 1, "wqkvT32", 2 * inner)] \
             if self.prec != PREC_F32 else []
         per_layer = sum(2 * r * c for _, r, c in mats) + sum(r * c for _, r, c, _, _, _ in mats32)
         layers = self._layers()
@@ -131,6 +152,7 @@ class Engine:
         maxel = 0
         for sname, l in layers:
             bw = MsstBlockWeights()
+            bw.struct_bytes = ctypes.sizeof(MsstBlockWeights)
             for name, r, c in mats:
                 src = self.fp.ptr(f"{sname}.{l}.{name}")
                 for tr in (0, 1):
@@ -140,10 +162,13 @@ class Engine:
                     off += r * c
                     j += 1
                     maxel = max(maxel, r * c)
-            for name, r, c, tr, field, pack in mats32:
+            for name, r, c, tr, field, scale_rows in mats32:
                 dst = base + off * esz
                 jobs[j].src, jobs[j].dst, jobs[j].rows, jobs[j].cols = self.fp.ptr(f"{sname}.{l}.{name}"), dst, r, c
-                jobs[j].transpose, jobs[j].pack = tr, pack
+                jobs[j].transpose, jobs[j].pack = tr, 1
+                jobs[j].scale_rows, jobs[j].scale = scale_rows, float(DH) ** -0.5
+                dr, dk = (c, r) if tr else (r, c)   # destination rows x contraction length: whole 32 x 16 fragments only
+                assert dr % 32 == 0 and dk % 16 == 0, (name, r, c, tr)
                 setattr(bw, field, dst)
                 off += r * c
                 j += 1

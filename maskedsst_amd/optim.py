@@ -202,11 +202,13 @@ def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
     model.dp_world = dist.get_world_size(group) if dist.is_initialized() else 1
     red = BucketReducer(eng.fp.grad, eng.fp.buckets, group=group, bucket_bytes=bucket_bytes)
     eng.bucket_hook = red.bucket_ready
-    # RCCL's channel workgroups need CUs of their own while the backward runs.  The attention backward fills every CU slot
-    # with a statically partitioned persistent grid: a workgroup that finds no slot runs as a second wave BEHIND the others
-    # and doubles that launch.  Measured with bench.py --cu-thief (profiles/r03_dp_cu_contention.jsonl: 8-32 probe
-    # workgroups held under the whole backward): step +19 % on the single-GPU grids, still +19 % with 16 or 24 CUs left
-    # free, +3.5 % with 32 -- and the smaller grids cost nothing measurable when nothing contends.  Hence 32.
+    # RCCL's channel workgroups need CUs of their own while the backward runs.  The backward's persistent grids fill every CU
+    # with ONE workgroup each and are statically partitioned: a workgroup that finds no CU runs BEHIND the others and doubles
+    # that launch.  Measured with bench.py --cu-thief (N probe workgroups, each holding a whole CU under the backward;
+    # profiles/r03_dp_cu_contention.jsonl, two-head attention backward): step 26.46 ms undisturbed; 33.6-33.7 ms (+27 %) with
+    # 8, 16 or 32 probes on the full grids; with 16 CUs left free 28.1 ms (+6 %) for 8 / 16 probes but 34.7 ms (+31 %) for 32;
+    # with 32 CUs left free 27.6-27.7 ms (+4.5 %) for all three.  Hence 32 (RCCL's default channel count on this node is below
+    # that); the r04 sweep (profiles/r04_dp_cu_contention.jsonl) adds the no-probe run on the reserved grids.
     if model.dp_world > 1 or os.environ.get("MSST_FORCE_DP", "0") == "1":
         eng.reserve_cus(int(os.environ.get("MSST_DP_RESERVE_CUS", "32")))
     return red
