@@ -102,6 +102,15 @@ __global__ __launch_bounds__(256) void reduce_segs_kernel(RSegs r) {
 #pragma unroll
                 for (int u = 0; u < 16; ++u) s = s + v[u];
             }
+            // the 64 slabs of the attention backward (and the 256 of the fused LN1 + MLP launch): eight requests in flight, ONE round
+            // trip per block instead of two serial rounds of four
+            for (; k + 56 < g.nslab; k += 64) {
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (long)(k + 8 * u) * g.slab_stride);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) s = s + v[u];
+            }
             for (; k + 24 < g.nslab; k += 32) {
                 const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (long)k * g.slab_stride);
                 const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + (long)(k + 8) * g.slab_stride);
@@ -1375,6 +1384,224 @@ __global__ __launch_bounds__(256) void tokenize_bwd_kernel(TokBwdArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same backward for the reference's shapes (P = 10, N = 64) on the fp32 matrix cores (round 4; forward:
+// tokenize_fwd_mfma_kernel).  The kernel above spends its time in LDS reads of the [96][P] weight (one per multiply-add, in
+// the forward recompute and in d(xn) = W^T de) and in a 64-deep serial loop per dW element: 230 us for 184 MB.  Here
+//   * wave w <-> tokens 16 w .. + 15 of spectral block c, persistent over the samples of its chunk: the position-gradient
+//     rows of those tokens accumulate in registers with no reduction at all;
+//   * forward recompute e = W xn + b: 18 MFMAs (weights as A operand from LDS-resident fragments);
+//   * d(xn)[k][token] = sum_d W[d][k] de[d][token]: 24 MFMAs whose B operand is the C-layout de as it stands (the contraction
+//     index runs over the features in the order the C layout hands them over; the A operand W^T is fetched in the same order);
+//   * dW[d][k] += sum_token de[d][token] xn[token][k]: 24 MFMAs over the wave's 16 tokens, both operands transposed through a
+//     wave-private LDS tile; a column of ones appended to xn makes dW[d][10] the bias gradient.
+// Slab layout as above.  grid (S, nchunk), 256 threads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void tokenize_bwd_mfma_kernel(TokBwdArgs a) {
+    constexpr int P = 10, N = 64;
+    __shared__ float wA[6][3][64];        // forward A fragments: [mt][ks][lane] = W[16 mt + (lane & 15)][4 ks + (lane >> 4)]
+    __shared__ float wT[6][4][64];        // d(xn) A fragments: [mt][r][lane] = W[16 mt + 4 (lane >> 4) + r][lane & 15] (0 for k >= 10)
+    __shared__ float vecs[2][96];         // bias | post_g
+    __shared__ float de_raw[4 * 96 * 17];  // wave-private de[feature][token] tiles in the walk; the epilogue's reduction array afterwards
+    __shared__ float xn_t[4][16][17];     // wave-private: xn[k][token] (row 10 = ones)
+    float (*de_t)[96][17] = reinterpret_cast<float (*)[96][17]>(de_raw);
+    float (*red)[97] = reinterpret_cast<float (*)[97]>(de_raw);   // [64][97] = 6208 floats <= 6528
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
+    const int T = a.T;
+    const float* Wc = a.w_emb + (long)c * 96 * P;
+    for (int i = tid; i < 6 * 3 * 64; i += 256) {
+        const int ln = i & 63, ks = (i >> 6) % 3, mt = i / 192, k = 4 * ks + (ln >> 4);
+        (&wA[0][0][0])[i] = k < P ? Wc[(16 * mt + (ln & 15)) * P + k] : 0.f;
+    }
+    for (int i = tid; i < 6 * 4 * 64; i += 256) {
+        const int ln = i & 63, r = (i >> 6) & 3, mt = i >> 8, k = ln & 15;
+        (&wT[0][0][0])[i] = k < P ? Wc[(16 * mt + 4 * (ln >> 4) + r) * P + k] : 0.f;
+    }
+    if (tid < 96) { vecs[0][tid] = a.b_emb[c * 96 + tid]; vecs[1][tid] = a.post_g[tid]; }
+    float pg[3], pb[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; pg[ks] = k < P ? a.pre_g[k] : 0.f; pb[ks] = k < P ? a.pre_b[k] : 0.f; }
+    __syncthreads();
+    const int n = 16 * w + j, t = c * N + n;
+    // persistent accumulators (C layout: lane (token j, g) <-> features 16 mt + 4 g + r)
+    f32x4 dpos[6], dpg[6], dpb[6], dW[6];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) { dpos[mt] = zero4(); dpg[mt] = zero4(); dpb[mt] = zero4(); dW[mt] = zero4(); }
+    f32x4 dprg = zero4(), dprb = zero4();   // pre_norm gamma / beta gradients of pixels k = 4 g + r (this lane's token)
+    const int nb = (int)gridDim.y;
+    float px[3], px2[4];
+    f32x4 drow[6];
+    unsigned char mk;
+    auto request = [&](int b) {
+        const int bc = b < a.B ? b : a.B - 1;
+        const float* src = a.img + ((long)bc * a.S + c) * P * N + n;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; px[ks] = src[(k < P ? k : 0) * N]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const int k = 4 * g + r; px2[r] = src[(k < P ? k : 0) * N]; }
+        mk = a.mask[(long)bc * T + t];
+    };
+    // the dx0 rows of the next sample are requested late in the iteration (behind the LayerNorm backward: 24 registers that are
+    // free only then), the pixels and the mask byte early
+    auto request_rows = [&](int b) {
+        const int bc = b < a.B ? b : a.B - 1;
+        const float* dsrc = a.dx0 + ((long)bc * T + t) * 96 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) drow[mt] = *reinterpret_cast<const f32x4*>(dsrc + 16 * mt);
+    };
+    request(chunk);
+    request_rows(chunk);
+    for (int b = chunk; b < a.B; b += nb) {
+        // lane indices re-derived from a laundered id every iteration: the weight fragments, the bias and post_norm's gamma are
+        // loop-invariant LDS reads -- with an invariant address they are hoisted out of the walk (90 registers) and spilled
+        int ll = threadIdx.x & 63;
+        asm volatile("" : "+v"(ll));
+        const int gl = ll >> 4, jl = ll & 15;
+        float x[3], x2[4];
+        f32x4 dt[6];
+        const bool masked = mk != 0;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) x[ks] = (4 * ks + g < P) ? px[ks] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x2[r] = px2[r];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            dt[mt] = drow[mt];
+            if (a.drop.thr) dt[mt] = drop4(a.drop, 0, (unsigned)(((long)b * T + t) * 24 + 4 * mt + g), dt[mt]);   // emb dropout backward
+        }
+        request(b + nb);
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) dpos[mt] = dpos[mt] + dt[mt];
+        // ---- recompute: LN(10), Linear(10 -> 96), LN(96) statistics ----
+        const float mean = colgroup_sum(x[0] + x[1] + x[2]) / P;
+        float var = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const float d = (4 * ks + g < P) ? x[ks] - mean : 0.f; var += d * d; }
+        const float rstd = rsqrtf(colgroup_sum(var) / P + 1e-5f);
+        float xn[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) xn[ks] = (4 * ks + g < P) ? (x[ks] - mean) * rstd * pg[ks] + pb[ks] : 0.f;
+        f32x4 e[6];
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            f32x4 acc = *reinterpret_cast<const f32x4*>(&vecs[0][16 * mt + 4 * gl]);
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[mt][ks][ll], xn[ks], acc, 0, 0, 0);
+            e[mt] = acc;
+            s += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        const float m2 = colgroup_sum(s) * (1.f / 96.f);
+        float v2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = e[mt][r] - m2; v2 += d * d; }
+        const float rstd2 = rsqrtf(colgroup_sum(v2) * (1.f / 96.f) + 1e-5f);
+        // ---- LN(96) backward; masked tokens: the gradient goes to the mask token only (and the position table, above) ----
+        float g1 = 0.f, g2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const f32x4 pg4 = *reinterpret_cast<const f32x4*>(&vecs[1][16 * mt + 4 * gl]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float eh = (e[mt][r] - m2) * rstd2;
+                e[mt][r] = eh;
+                const float d = masked ? 0.f : dt[mt][r];
+                dpg[mt][r] += d * eh;
+                dpb[mt][r] += d;
+                const float dg = d * pg4[r];
+                dt[mt][r] = dg;
+                g1 += dg;
+                g2 += dg * eh;
+            }
+        }
+        g1 = colgroup_sum(g1) * (1.f / 96.f);
+        g2 = colgroup_sum(g2) * (1.f / 96.f);
+        // de[feature][token] (C layout) -> the wave's LDS tile; d(xn) = W^T de on the matrix cores
+        float* det = &de_t[w][4 * gl][jl];
+        f32x4 dxn = zero4();   // C[i = pixel k = 4 g + r][j = token]
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float de = rstd2 * (dt[mt][r] - g1 - e[mt][r] * g2);
+                det[(16 * mt + r) * 17] = de;
+                dxn = __builtin_amdgcn_mfma_f32_16x16x4f32(wT[mt][r][ll], de, dxn, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) xn_t[w][4 * ks + gl][jl] = (4 * ks + gl == P) ? 1.0f : xn[ks];   // row 10: ones -> bias gradient
+        request_rows(b + nb);
+        // pre_norm gamma / beta: pixels k = 4 g + r of this lane's token
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool ok = 4 * g + r < P;
+            const float xh = ok ? (x2[r] - mean) * rstd : 0.f;
+            dprg[r] += ok ? dxn[r] * xh : 0.f;
+            dprb[r] += ok ? dxn[r] : 0.f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dW[d][k] += sum over the wave's 16 tokens: A[i = feature][kk = token], B[j = pixel k][kk = token]
+        const float* dea = &de_t[w][jl][gl];
+        const float* xna = &xn_t[w][jl][gl];
+#pragma unroll
+        for (int ts = 0; ts < 4; ++ts) {
+            const float bx = xna[4 * ts];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) dW[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(dea[16 * mt * 17 + 4 * ts], bx, dW[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---------------- slab ----------------
+    const int slab_n = N * 96 + 96 * P + 96 * 4 + 32;
+    float* slab = a.slab + ((long)c * gridDim.y + chunk) * slab_n;
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) *reinterpret_cast<f32x4*>(slab + n * 96 + 16 * mt + 4 * g) = dpos[mt];
+    float* vec = slab + N * 96 + 96 * P;
+    // dW: C[i = feature 16 mt + 4 g + r][j = pixel k]; the four waves' tiles are summed through LDS (column k = 10 is the bias gradient)
+    __syncthreads();
+    for (int which = 0; which < 4; ++which) {   // the four waves take turns adding their dW tile into red[feature][k]
+        if (w == which) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* cell = &red[0][0] + (16 * mt + 4 * g + r) * 17 + j;
+                    *cell = which == 0 ? dW[mt][r] : *cell + dW[mt][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < 96 * P; i += 256) { const int d = i / P, k = i - d * P; slab[N * 96 + i] = (&red[0][0])[d * 17 + k]; }
+    if (tid < 96) vec[tid] = (&red[0][0])[tid * 17 + P];   // db
+    // per-feature column sums over the 64 tokens: dpost_g, dpost_b, dmask = sum(dpos) - dpost_b
+    for (int which = 0; which < 3; ++which) {
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[n][16 * mt + 4 * g + r] = which == 0 ? dpg[mt][r] : which == 1 ? dpb[mt][r] : dpos[mt][r] - dpb[mt][r];
+        __syncthreads();
+        if (tid < 96) {
+            float sres = 0.f;
+            for (int rr = 0; rr < 64; ++rr) sres += red[rr][tid];
+            vec[(which + 1) * 96 + tid] = sres;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { red[n][4 * g + r] = dprg[r]; red[n][16 + 4 * g + r] = dprb[r]; }
+    __syncthreads();
+    if (tid < 32) {
+        float sres = 0.f;
+        for (int rr = 0; rr < 64; ++rr) sres += red[rr][tid];
+        vec[4 * 96 + tid] = sres;
+    }
+}
+
 // position-table gradient for the factorised (spectral_pos_embed) table:
 // dpos_embed[n][0:split] = sum_c dpos[c][n][0:split]; dchannel_embed[c][0:96-split] = sum_n dpos[c][n][split:96]
 __global__ __launch_bounds__(256) void pos_split_kernel(const float* dpos /*[S][N][96]*/, int S, int N, int split,
@@ -1479,7 +1706,8 @@ int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st
 int launch_tokenize_bwd(const TokBwdArgs& a, int nchunk, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
     ProfScope ps(K_TOK_BWD, st);
-    if (a.P == 10) hipLaunchKernelGGL(tokenize_bwd_kernel<10>, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    if (a.P == 10 && a.N == 64) hipLaunchKernelGGL(tokenize_bwd_mfma_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    else if (a.P == 10) hipLaunchKernelGGL(tokenize_bwd_kernel<10>, dim3(a.S, nchunk), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(tokenize_bwd_kernel<0>, dim3(a.S, nchunk), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }

@@ -89,6 +89,112 @@ __global__ __launch_bounds__(256) void tokenize_fwd_kernel(TokArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same tokenizer for the reference's shapes (P = 10 pixels per patch, N = 64 spatial tokens) on the fp32 matrix cores
+// (round 4).  The kernel above reads its [96][P] weight from LDS once per multiply-add (240 four-byte LDS reads per thread and
+// token) and re-stages that weight for every sample: 100 us for 141 MB.  Here the per-block Linear(P -> 96) of 16 tokens is
+// 18 v_mfma_f32_16x16x4_f32 (exact fp32, the fmaf chain of the reference's addmm): weights as the A operand -- 18 registers
+// per lane, loaded once per workgroup and kept for its whole walk over the batch -- the LN(10)-normalised pixels as the B
+// operand straight from the lane that loaded them (lane (j, g) holds pixels 4 ks + g of token j: exactly the 16x16x4 B
+// layout), and the C layout (4 consecutive features of one token per lane) is the 16-byte store of the token row.
+// grid (S, nchunk), 256 threads: wave w <-> tokens 16 w .. + 15 of spectral block c, samples chunk, chunk + nchunk, ...
+// Position rows, bias, both LayerNorms' vectors and the mask token are tile invariant for a wave: registers / LDS.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void tokenize_fwd_mfma_kernel(TokArgs a) {
+    constexpr int P = 10, N = 64;
+    __shared__ __attribute__((aligned(16))) float vec[3][96];   // post_g | post_b | mask_token
+    const int c = blockIdx.x, tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
+    if (tid < 96) { vec[0][tid] = a.post_g[tid]; vec[1][tid] = a.post_b[tid]; vec[2][tid] = a.mask_token[tid]; }
+    // A fragments of W_c [96][10]: lane (i = l & 15, kq = l >> 4) holds W[16 mt + i][4 ks + kq] (zero beyond k = 9)
+    float wf[6][3];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int k = 4 * ks + g;
+            wf[mt][ks] = k < P ? a.w_emb[((long)c * 96 + 16 * mt + j) * P + k] : 0.f;
+        }
+    float pg[3], pb[3];
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; pg[ks] = k < P ? a.pre_g[k] : 0.f; pb[ks] = k < P ? a.pre_b[k] : 0.f; }
+    // C layout: lane (token j, g) holds features 16 mt + 4 g + r
+    const int n = 16 * w + j, t = c * N + n;
+    f32x4 bias4[6], pos4[6];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) {
+        const int d0 = 16 * mt + 4 * g;
+        bias4[mt] = *reinterpret_cast<const f32x4*>(a.b_emb + c * 96 + d0);
+        if (a.pos_split) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d = d0 + r;
+                pos4[mt][r] = d < a.pos_split ? a.pos_a[n * a.pos_split + d] : a.pos_b[c * (96 - a.pos_split) + d - a.pos_split];
+            }
+        } else {
+            pos4[mt] = *reinterpret_cast<const f32x4*>(a.pos_a + (long)t * 96 + d0);
+        }
+    }
+    __syncthreads();
+    const int nb = (int)gridDim.y;
+    float px[3];
+    unsigned char mk;
+    auto request = [&](int b) {
+        const int bc = b < a.B ? b : a.B - 1;
+        const float* src = a.img + ((long)bc * a.S + c) * P * N + n;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const int k = 4 * ks + g; px[ks] = src[(k < P ? k : 0) * N]; }
+        mk = a.mask[(long)bc * a.T + t];
+    };
+    request(blockIdx.y);
+    for (int b = blockIdx.y; b < a.B; b += nb) {
+        float x[3];
+        const bool masked = mk != 0;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) x[ks] = (4 * ks + g < P) ? px[ks] : 0.f;
+        request(b + nb);
+        // LN over the 10 pixels of the token (pre_norm, eps 1e-5): 3 (2) per lane, summed over the four lanes l, l ^ 16, l ^ 32, l ^ 48
+        const float mean = colgroup_sum(x[0] + x[1] + x[2]) / P;
+        float var = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const float d = (4 * ks + g < P) ? x[ks] - mean : 0.f; var += d * d; }
+        const float rstd = rsqrtf(colgroup_sum(var) / P + 1e-5f);
+        float xn[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) xn[ks] = (4 * ks + g < P) ? (x[ks] - mean) * rstd * pg[ks] + pb[ks] : 0.f;
+        // per-block Linear(10 -> 96) + bias: C[i = feature][j = token]
+        f32x4 e[6];
+        float s = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            f32x4 acc = bias4[mt];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[mt][ks], xn[ks], acc, 0, 0, 0);
+            e[mt] = acc;
+            s += (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        }
+        const float m2 = colgroup_sum(s) * (1.f / 96.f);
+        float v2 = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float d = e[mt][r] - m2; v2 += d * d; }
+        const float rstd2 = rsqrtf(colgroup_sum(v2) * (1.f / 96.f) + 1e-5f);
+        float* dst = a.out + ((long)b * a.T + t) * 96 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            const int d0 = 16 * mt + 4 * g;
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(&vec[0][d0]), b4 = *reinterpret_cast<const f32x4*>(&vec[1][d0]),
+                        m4 = *reinterpret_cast<const f32x4*>(&vec[2][d0]);
+            f32x4 v;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (masked ? m4[r] : (e[mt][r] - m2) * rstd2 * g4[r] + b4[r]) + pos4[mt][r];
+            if (a.drop.thr) v = drop4(a.drop, 0, (unsigned)(((long)b * a.T + t) * 24 + 4 * mt + g), v);   // emb dropout (group = feature / 4)
+            *reinterpret_cast<f32x4*>(dst + 16 * mt) = v;
+        }
+    }
+}
+
 // ==========================================================================================
 // fused transformer block, forward.  Reference vit_spatial_spectral.py:22-29 (PreNorm),
 // :47-78 (Attention: bias-free qkv, q|k|v chunks, head-major (h d), softmax(q k^T * dh^-0.5) v,
@@ -746,7 +852,12 @@ __global__ __launch_bounds__(256) void loss_reduce_kernel(const float* partial, 
 int launch_tokenize_fwd(const TokArgs& a, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
     ProfScope ps(K_TOK_FWD, st);
-    if (a.P == 10) hipLaunchKernelGGL(tokenize_fwd_kernel<10>, dim3(a.S, a.B), dim3(256), 0, st, a);
+    if (a.P == 10 && a.N == 64) {   // the reference's shapes: fp32 matrix cores, persistent over the batch
+        int nchunk = 1024 / (a.S > 0 ? a.S : 1);
+        if (nchunk < 1) nchunk = 1;
+        if (nchunk > a.B) nchunk = a.B;
+        hipLaunchKernelGGL(tokenize_fwd_mfma_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    } else if (a.P == 10) hipLaunchKernelGGL(tokenize_fwd_kernel<10>, dim3(a.S, a.B), dim3(256), 0, st, a);
     else hipLaunchKernelGGL(tokenize_fwd_kernel<0>, dim3(a.S, a.B), dim3(256), 0, st, a);
     return (int)hipGetLastError();
 }
