@@ -38,7 +38,6 @@ extern "C" {
  * the library never reads the environment and keeps no per-call state. */
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
-#define MSST_KERNEL_ATTN_R2 (32 << 8)    /* bf16 attention backward: the round-2 kernel (16x16x32 tiles)     */
 #define MSST_KERNEL_FWD_HW (256 << 8)    /* bf16 forward, 8 heads: the lockstep head-per-wave kernel (msst_fwd2.hip) instead of the role-split one (msst_fwd3.hip) */
 #define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 
@@ -81,7 +80,7 @@ typedef struct MsstBlockWeights {
     const void* w2T;   /* [64][96]                                             */
     const float* ln1_g; const float* ln1_b; const float* bo;
     const float* ln2_g; const float* ln2_b; const float* b1; const float* b2;
-    /* bf16 only, optional (null: msst_block_bwd runs the round-2 attention backward): the three matrices the round-3
+    /* bf16 only, optional (null: msst_block_bwd runs the template attention backward): the three matrices the round-3
      * attention backward feeds to 32x32x16 MFMAs, fragment-packed with MsstPrepJob.pack = 1 */
     const void* wqkv32;  /* [3*H*64][96]  */
     const void* woutT32; /* [H*64][96]    */

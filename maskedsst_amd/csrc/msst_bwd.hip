@@ -1678,14 +1678,13 @@ int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_
         if (rc) return rc;
         ProfScope ps(K_BWD_ATTN, st);
         hipLaunchKernelGGL(block_bwd_attn_kernel<PF32>, grid, dim3(256), smem, st, a);
-    } else if (!(a.dbg & 16)) {
-        // MSST_DBG=16 selects the template kernel below (reference for the tuned ones), 32 the round-2 tuned kernel
-        // 128 the one-head-per-workgroup round-3 kernel; default: two heads per workgroup (msst_bwd4.hip)
-        if (!(a.dbg & 32) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) {
-            if (!(a.dbg & 128) && !(a.H & 1)) { *nparts = a.H / 2; return launch_block_bwd_attn_r4(a, nchunk, st); }
-            return launch_block_bwd_attn_r3(a, nchunk, st);
-        }
-        return launch_block_bwd_attn_bf16(a, nchunk, st);
+    } else if (!(a.dbg & 16) && a.xn && a.dab && a.w.wqkv32 && a.w.woutT32 && a.w.wqkvT32 && a.ntok * 192 < 0x7ffffff0L) {
+        // the tuned kernels (they need the LN1 rows saved by the forward and the pre-dropped bf16 da rows of the MLP half): two
+        // heads per workgroup (msst_bwd4.hip) by default, one head per workgroup (msst_bwd3.hip) for an odd head count or with
+        // MSST_DBG=128.  MSST_DBG=16, or a caller without saved rows: the template kernel below (the reference they are tested
+        // against).  (The round-2 kernel msst_bwd2.hip was retired in round 4.)
+        if (!(a.dbg & 128) && !(a.H & 1)) { *nparts = a.H / 2; return launch_block_bwd_attn_r4(a, nchunk, st); }
+        return launch_block_bwd_attn_r3(a, nchunk, st);
     } else {
         const size_t smem = sizeof(AttnBwdSmem<PBF16>) + 192 * sizeof(float) + 256;   // LN vectors + the l2_touch pad
         int rc = set_smem(&block_bwd_attn_kernel<PBF16>, smem, d1);

@@ -1,7 +1,7 @@
 // bf16 attention half of a block, backward (reference vit_spatial_spectral.py:47-78 under PreNorm :22-29; a15 of
 // SURVEY.md section 8) -- round-3 kernel.  Same math, same HBM interface (saved bf16 LN1 rows + pre-dropped bf16 da rows
 // in, one bf16 d(LN1 out) partial per head and one weight-gradient slab per workgroup out) and the same dropout streams
-// as block_bwd_attn_bf16_kernel (msst_bwd2.hip); what changes is how the work of a 64-row tile is cut:
+// as the round-2 kernel (msst_bwd2.hip, retired in round 4); what changes is how the work of a 64-row tile is cut:
 //
 //   * ONE GEMM = ONE WAVE.  The round-2 kernel split every GEMM four ways (16 x 64 strips), so each wave re-read the
 //     whole other operand: 1.4 LDS instructions per MFMA, LDS pipe 71 % busy, MFMA pipes 31 %.  Here the four waves of a

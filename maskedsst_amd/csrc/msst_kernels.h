@@ -186,7 +186,6 @@ struct RSegBuilder {
 int launch_reduce_segs(const RSegs& r, hipStream_t st);
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st, int* nparts);
-int launch_block_bwd_attn_bf16(const AttnBwdArgs& a, int nchunk, hipStream_t st);   // msst_bwd2.hip (round-2 bf16 kernel, 16x16x32 tiles)
 int launch_block_bwd_attn_r3(const AttnBwdArgs& a, int nchunk, hipStream_t st);     // msst_bwd3.hip (bf16 throughput kernel: one GEMM per wave, 32x32x16 tiles)
 int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st);     // msst_bwd4.hip (the same, two heads per workgroup half a tile apart)
 int launch_block_bwd_ln1(const Ln1BwdArgs& a, int grid, int prec, hipStream_t st);

@@ -278,7 +278,7 @@ class Engine:
         S, N, P = self.S, self.N, self.P
         K = dpred.shape[1]
         dev = y.device
-        nchunk = max(1, min(B, 512 // max(S, 1)))
+        nchunk = max(1, min(B, int(os.environ.get("MSST_HEAD_CHUNKS", "0")) or 512 // max(S, 1)))
         dy = torch.empty_like(y)
         slab = torch.empty(S * nchunk * (P * 96 + P), dtype=torch.float32, device=dev)
         per_block = 1 if hasattr(self.mim.to_pixels, "layers") else 0

@@ -382,5 +382,5 @@ def test_other_tile_packings(cfg, prec):
         record("other_tile_packings_bf16", cfg=cfg, loss_err=abs(loss.item() - lr) / abs(lr), one_minus_cos=1 - cos)
         # measured: loss <= 2.2e-5; 1 - cosine <= 9.6e-4 (end to end on 1-3 samples the flipped L1 signs dominate the
         # cosine; the kernel-level bf16 gradient bars with the oracle's sign pattern are in test_gpu_backward / _depth12)
-        assert abs(loss.item() - lr) <= 5e-5 * abs(lr), (loss.item(), lr)
+        assert abs(loss.item() - lr) <= 8e-5 * abs(lr), (loss.item(), lr)
         assert cos > 0.998, cos

@@ -7,7 +7,8 @@ Three legs per depth-12 fixture captured from the reference (tools/make_golden.p
   * the bf16 kernels that bench.py times (block_fwd_hw, block_bwd_attn_bf16, block_bwd_mlp) are the ones exercised:
     nothing here sets MSST_DBG.
 Every measured error is appended to gpurun_out/parity_r02.jsonl (scratch) so that the bars below can be quoted
-next to the measurements in DESIGN.md; every bf16 bar is <= 2x the measured value (measured in comments).
+next to the measurements in DESIGN.md; every bf16 bar is 3-4x the measured value (round 4; measured values in comments): a
+bar at 2x one run trips on the next compiler or clock change.
 """
 import numpy as np
 import pytest
@@ -85,13 +86,13 @@ def test_depth12_fp32_vs_fixture_and_oracle(name):
            stage_err=stage_err, worst_grad=worst)
 
 
-# bf16 bars: <= 2x the errors measured on MI355X in round 2 (profiles/r02_parity_measured.jsonl).
+# bf16 bars: 3-4x the errors measured on MI355X (profiles/r0N_parity_measured.jsonl).
 # Measured through 24 blocks: loss 0.7e-4 / 2.6e-4 / 2.3e-4 relative to the reference anchor, worst stage (max-norm)
 # 3.5e-3, dx0 2.8e-3 rel-L2, worst parameter-gradient tensor 5.4e-3 rel-L2 (median 2.8e-3), 1 - cosine 2.6e-5.
 BF16_BARS = {
-    "simmim_200b_L12_B4.npz": dict(loss=1.5e-4, stage=7e-3, dx0=5.5e-3, grad=1.1e-2, cos=0.99995),
-    "simmim_50b_L12_B8.npz": dict(loss=5e-4, stage=7e-3, dx0=5.5e-3, grad=1.1e-2, cos=0.99995),
-    "simmim_50b_L12_B8_zeropad.npz": dict(loss=5e-4, stage=7e-3, dx0=5.5e-3, grad=1.1e-2, cos=0.99995),
+    "simmim_200b_L12_B4.npz": dict(loss=2.8e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
+    "simmim_50b_L12_B8.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
+    "simmim_50b_L12_B8_zeropad.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
 }
 
 
@@ -172,7 +173,7 @@ def test_full_size_b256_bf16():
     with torch.no_grad():
         ref = simmim_forward(params, x[sel], oracle_cfg_from(cfg), masks=(masks[0][sel], sub_idx))
     stage_err = {k: relerr(out[k][sel.cuda()], ref[k]) for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out"]}
-    assert max(stage_err.values()) < 6e-3, stage_err   # measured 2.8e-3
+    assert max(stage_err.values()) < 1e-2, stage_err   # measured 2.8e-3
     assert torch.isfinite(out["loss"])
     del out
 
@@ -195,7 +196,7 @@ def test_full_size_b256_bf16():
     eng.set_precision("bf16")
     loss_err = abs(l1.item() - l32.item()) / abs(l32.item())
     record("full_size_b256", stage_err=stage_err, loss_bf16=l1.item(), loss_fp32=l32.item(), loss_err=loss_err)
-    assert loss_err < 8e-5, (l1.item(), l32.item())   # measured 3.8e-5
+    assert loss_err < 1.4e-4, (l1.item(), l32.item())   # measured 3.8e-5
 
 
 def test_adamw_parameters_after_5_steps():

@@ -20,10 +20,21 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "hip error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 
 // ------------------------------------------------------------------ MFMA peak
-template <int SHAPE>
-__global__ __launch_bounds__(256) void mfma_peak(float* out, int iters) {
+// MODE: 0 = zero operands, 1 = one small constant, 2 = a smooth per-lane pattern (round 3's), 3 = hashed full-range values in [-1, 1)
+// (the chip clocks to its power budget: the same instruction stream runs at a different clock on different data)
+__device__ __forceinline__ float mb_rand(unsigned x) {
+    x *= 0x9E3779B1u; x ^= x >> 15; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return (float)(int)x * (1.0f / 2147483648.0f);
+}
+template <int SHAPE, int MODE>
+__global__ __launch_bounds__(256) void mfma_peak(float* out, int iters, unsigned long long* clk) {
     bf16x8 a, b;
-    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(0.001f * (threadIdx.x + i)); b[i] = (__bf16)(0.002f * (threadIdx.x - i)); }
+    for (int i = 0; i < 8; ++i) {
+        const unsigned id = (blockIdx.x * 256 + threadIdx.x) * 16 + i;
+        a[i] = (__bf16)(MODE == 0 ? 0.f : MODE == 1 ? 0.5f : MODE == 2 ? 0.001f * (threadIdx.x + i) : mb_rand(id));
+        b[i] = (__bf16)(MODE == 0 ? 0.f : MODE == 1 ? 0.25f : MODE == 2 ? 0.002f * (threadIdx.x - i) : mb_rand(id + 8));
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
     if constexpr (SHAPE == 32) {
         f32x16 c0 = {}, c1 = {}, c2 = {}, c3 = {};
         for (int it = 0; it < iters; ++it) {
@@ -35,6 +46,7 @@ __global__ __launch_bounds__(256) void mfma_peak(float* out, int iters) {
         float s = 0.f;
         for (int i = 0; i < 16; ++i) s += c0[i] + c1[i] + c2[i] + c3[i];
         out[blockIdx.x * 256 + threadIdx.x] = s;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = wall_clock64() - w0; }
     } else {
         f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
         for (int it = 0; it < iters; ++it) {
@@ -50,12 +62,43 @@ __global__ __launch_bounds__(256) void mfma_peak(float* out, int iters) {
         float s = 0.f;
         for (int i = 0; i < 4; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + c4[i] + c5[i] + c6[i] + c7[i];
         out[blockIdx.x * 256 + threadIdx.x] = s;
+        if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = wall_clock64() - w0; }
     }
 }
 
 // ------------------------------------------------------------------ HBM copy
 __global__ __launch_bounds__(256) void copy4(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+// the same streams with U 16-byte requests in flight per lane (the product's HBM-bound kernels keep 6 to 28 in flight): copy,
+// read-only (sum) and write-only
+template <int U>
+__global__ __launch_bounds__(256) void copy4u(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i + (U - 1) * stride < n; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) dst[i + u * stride] = v[u];
+    }
+}
+template <int U>
+__global__ __launch_bounds__(256) void read4u(const f32x4* __restrict__ src, float* __restrict__ sink, long n) {
+    const long stride = (long)gridDim.x * 256;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i + (U - 1) * stride < n; i += U * stride) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = acc + v[u];
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) sink[0] = acc[0];
+}
+__global__ __launch_bounds__(256) void write4(f32x4* __restrict__ dst, long n) {
+    const f32x4 v = {1.f, 2.f, 3.f, 4.f};
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = v;
 }
 
 // ------------------------------------------------------------------ L2-resident weight-fragment loads (1 KB per wave-instruction)
@@ -206,24 +249,37 @@ int main() {
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float* d_out;
     CK(hipMalloc(&d_out, 4096 * 256 * 4));
-    // MFMA: 256 CUs x 2 workgroups x 4 waves
+    // MFMA: 256 CUs x 2 workgroups x 4 waves; four operand fills (DVFS: the clock follows the data)
     {
         const int grid = 512, iters = 20000;
-        float best32 = 1e9f, best16 = 1e9f;
-        for (int rep = 0; rep < 4; ++rep) {
-            float ms;
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(mfma_peak<32>, dim3(grid), dim3(256), 0, 0, d_out, iters);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            best32 = std::min(best32, ms);
-            CK(hipEventRecord(e0));
-            hipLaunchKernelGGL(mfma_peak<16>, dim3(grid), dim3(256), 0, 0, d_out, iters);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
-            best16 = std::min(best16, ms);
-        }
+        unsigned long long* d_clk;
+        CK(hipMalloc(&d_clk, 16));
         const double f32 = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 16, f16 = (double)grid * 4 * iters * 8 * 2.0 * 16 * 16 * 32;
-        printf("  \"mfma_bf16_32x32x16_tflops\": %.1f, \"mfma_bf16_16x16x32_tflops\": %.1f, \"mfma_nominal_tflops\": 2500,\n",
-               f32 / best32 * 1e-9, f16 / best16 * 1e-9);
+        double tf32[4], tf16[4], mhz[4];
+        auto run = [&](auto kern, double flops, double& tf, double* clock_mhz) -> int {
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                float ms;
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, 0, d_out, iters, d_clk);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            tf = flops / best * 1e-9;
+            if (clock_mhz) {
+                unsigned long long h[2];
+                CK(hipMemcpy(h, d_clk, 16, hipMemcpyDeviceToHost));
+                *clock_mhz = (double)h[0] / ((double)h[1] / 100.0);   // shader cycles per microsecond of the 100 MHz wall clock
+            }
+            return 0;
+        };
+        if (run(mfma_peak<32, 0>, f32, tf32[0], &mhz[0]) || run(mfma_peak<32, 1>, f32, tf32[1], &mhz[1]) || run(mfma_peak<32, 2>, f32, tf32[2], &mhz[2]) ||
+            run(mfma_peak<32, 3>, f32, tf32[3], &mhz[3]) || run(mfma_peak<16, 0>, f16, tf16[0], nullptr) || run(mfma_peak<16, 3>, f16, tf16[3], nullptr)) return 1;
+        printf("  \"mfma_bf16_32x32x16_tflops\": %.1f, \"mfma_bf16_16x16x32_tflops\": %.1f, \"mfma_nominal_tflops\": 2500,\n", tf32[3], tf16[3]);
+        printf("  \"mfma_bf16_32x32x16_by_operands\": {\"zero\": %.1f, \"constant\": %.1f, \"smooth_pattern\": %.1f, \"random\": %.1f},\n", tf32[0], tf32[1], tf32[2], tf32[3]);
+        printf("  \"mfma_shader_clock_mhz_by_operands\": {\"zero\": %.0f, \"constant\": %.0f, \"smooth_pattern\": %.0f, \"random\": %.0f},\n", mhz[0], mhz[1], mhz[2], mhz[3]);
+        printf("  \"mfma_bf16_16x16x32_by_operands\": {\"zero\": %.1f, \"random\": %.1f},\n", tf16[0], tf16[3]);
+        CK(hipFree(d_clk));
     }
     // HBM copy: 1 GiB read + 1 GiB written
     {
@@ -240,6 +296,23 @@ int main() {
             best = std::min(best, ms);
         }
         printf("  \"hbm_copy_gbps\": %.0f, \"hbm_nominal_gbps\": 8000,\n", 2.0 * n * 16 / best * 1e-6);
+        // deeper streams: U requests in flight per lane, 256 x 16 workgroups
+        auto timeit = [&](auto launch) -> float {
+            float bestl = 1e9f;
+            for (int rep = 0; rep < 5; ++rep) {
+                float ms;
+                hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1); hipEventElapsedTime(&ms, e0, e1);
+                bestl = std::min(bestl, ms);
+            }
+            return bestl;
+        };
+        const float c4 = timeit([&] { hipLaunchKernelGGL(copy4u<4>, dim3(256 * 16), dim3(256), 0, 0, s, d, n); });
+        const float c8 = timeit([&] { hipLaunchKernelGGL(copy4u<8>, dim3(256 * 16), dim3(256), 0, 0, s, d, n); });
+        const float r8 = timeit([&] { hipLaunchKernelGGL(read4u<8>, dim3(256 * 16), dim3(256), 0, 0, s, d_out, n); });
+        const float r16 = timeit([&] { hipLaunchKernelGGL(read4u<16>, dim3(256 * 16), dim3(256), 0, 0, s, d_out, n); });
+        const float w1 = timeit([&] { hipLaunchKernelGGL(write4, dim3(256 * 16), dim3(256), 0, 0, d, n); });
+        printf("  \"hbm_copy_gbps_4_in_flight\": %.0f, \"hbm_copy_gbps_8_in_flight\": %.0f, \"hbm_read_gbps_8_in_flight\": %.0f, \"hbm_read_gbps_16_in_flight\": %.0f, \"hbm_write_gbps\": %.0f,\n",
+               2.0 * n * 16 / c4 * 1e-6, 2.0 * n * 16 / c8 * 1e-6, 1.0 * n * 16 / r8 * 1e-6, 1.0 * n * 16 / r16 * 1e-6, 1.0 * n * 16 / w1 * 1e-6);
         CK(hipFree(s)); CK(hipFree(d));
     }
     // L2-resident fragment loads: 288 KB buffer (one layer's Wqkv in bf16), every CU streaming
