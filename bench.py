@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--thief-reserve", type=int, default=-1,
                     help="with --cu-thief: size the backward's persistent grids for this many CUs left free (Engine.reserve_cus, "
                          "what attach_data_parallel does); -1 keeps the single-GPU grids")
+    ap.add_argument("--tile-queue", action="store_true",
+                    help="backward persistent grids draw their tiles from a queue (what attach_data_parallel selects) instead of the static partition")
     ap.add_argument("--force-dp", action="store_true",
                     help="single process, but through the data-parallel path: a one-rank RCCL process group, bucket hooks, "
                          "all-reduce calls, mean inside AdamW (MSST_FORCE_DP=1); for traces of the DP wiring on a 1-GPU box")
@@ -123,6 +125,8 @@ def main():
     opt = FusedAdamW(model, lr=0.008, weight_decay=0.05, grad_clamp=1.0)
     reducer = attach_data_parallel(model) if dist.is_initialized() else None
 
+    if args.tile_queue:
+        model.engine().tile_queue = True
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(SEED + rank)
     img = torch.randn(B, args.bands, 8, 8, generator=g).to(dev)   # synthetic cubes, resident in HBM
@@ -256,7 +260,8 @@ def main():
             out["forced_dp"] = True
         if args.cu_thief:
             out["cu_thief"] = {"workgroups": args.cu_thief, "hold_us": args.thief_us, "reserved_cus": args.thief_reserve,
-                               "attn_chunks": model.engine().attn_chunks, "grid_rows": model.engine().grid_rows}
+                               "attn_chunks": model.engine().attn_chunks, "grid_rows": model.engine().grid_rows,
+                               "tile_queue": bool(model.engine().tile_queue)}
         if pipe is not None:
             out["pipeline_inclusive"] = pipe
         if kernels:
@@ -271,7 +276,7 @@ def main():
             # HBM bytes per launch: NOT measured in this run (PMC counters need rocprofv3 passes of their own); read from the
             # committed summary of the PMC passes of this same command and labelled as such
             traffic, traffic_source = None, None
-            for tf in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            for tf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
                 try:
                     tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                     if B == 256 and args.bands == 200 and args.depth == 12 and args.precision == "bf16" and dom in tj["kernels"]:
@@ -280,18 +285,23 @@ def main():
                         break
                 except Exception:
                     continue
-            peak_measured = None
+            peak_measured, peak_file, pm = None, None, {}
             hbm_measured = None
-            try:
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r03_peak_microbench.json")))
-                peak_measured = pm.get("mfma_bf16_32x32x16_tflops") if args.precision == "bf16" else None
-                hbm_measured = pm.get("hbm_copy_gbps")
-            except Exception:
-                pass
+            for pf in ("r04_peak_microbench.json", "r03_peak_microbench.json"):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                    peak_measured = pm.get("mfma_bf16_32x32x16_tflops") if args.precision == "bf16" else None
+                    hbm_measured = pm.get("hbm_copy_gbps")
+                    peak_file = pf
+                    break
+                except Exception:
+                    continue
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
                                "peak_measured": peak_measured,
-                               "peak_measured_source": "profiles/r03_peak_microbench.json (tools/peak_microbench.hip on an MI355X of this pool: "
-                                                       "back-to-back 32x32x16 bf16 MFMAs on random operands; committed, not measured in this run)",
+                               "peak_measured_source": f"profiles/{peak_file} (tools/peak_microbench.hip on an MI355X of this pool: back-to-back "
+                                                       "32x32x16 bf16 MFMAs on hashed full-range operands -- the chip clocks to its power budget, "
+                                                       f"{pm.get('mfma_shader_clock_mhz_by_operands', {}).get('random', '?')} MHz on such data against 2400 nominal; "
+                                                       "committed, not measured in this run)",
                                "frac_of_measured_peak": round(achieved / peak_measured, 4) if peak_measured else None,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": traffic_source,
@@ -302,16 +312,21 @@ def main():
                                   "share": round(min(1.0, every * v["total_ms"] / (1e3 * elapsed)), 4)} for k, v in kernels.items()}
             # HBM-bound kernels: GB/s = committed PMC bytes per launch (same command) / this run's average launch time
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")))["kernels"]
+                tj = {}
+                for tf in ("r04_pmc_traffic.json", "r03_pmc_traffic.json"):
+                    if os.path.exists(os.path.join(ROOT, "profiles", tf)):
+                        tj = json.load(open(os.path.join(ROOT, "profiles", tf)))["kernels"]
+                        break
                 times = dict(survey)
                 times.update(kernels)
                 if B == 256 and args.bands == 200 and args.depth == 12 and args.precision == "bf16":
                     out["hbm_bound_kernels"] = {
                         k: {"gbps": round(tj[k]["hbm_bytes_per_launch"] / (times[k]["avg_us"] * 1e-6) / 1e9, 0),
                             "avg_us": round(times[k]["avg_us"], 2), "bytes_per_launch": tj[k]["hbm_bytes_per_launch"]}
-                        for k in ("block_bwd_ln1", "block_bwd_mlp", "tokenize_fwd", "tokenize_bwd", "head_bwd", "adamw", "reduce_slabs")
+                        for k in ("block_bwd_ln1mlp", "block_bwd_ln1", "block_bwd_mlp", "tokenize_fwd", "tokenize_bwd", "head_bwd", "adamw", "reduce_slabs")
                         if k in tj and k in times}
-                    out["hbm_peak"] = {"nominal_gbps": 8000, "measured_copy_gbps": hbm_measured}
+                    out["hbm_peak"] = {"nominal_gbps": 8000, "guide_achievable_gbps": 6290, "measured_copy_gbps": hbm_measured,
+                                       "measured_read_gbps": pm.get("hbm_read_gbps_8_in_flight"), "measured_write_gbps": pm.get("hbm_write_gbps")}
             except Exception:
                 pass
             if survey and not args.profile_all:   # untimed warmup steps, every kernel bracketed

@@ -172,13 +172,19 @@ int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /
  * Gradients of block i are complete when the call for block i returns (its MLP-half gradients were written by the call
  * before).  Requires prec = MSST_PREC_BF16 (tuned kernels), xn_saved and dab_ws, and at most four d(LN1 out) partials
  * (heads <= 8 even, or heads <= 4): MSST_ERR_BADARG / MSST_ERR_UNSUPPORTED otherwise -- use msst_block_bwd then.
- * slab: grid_rows*(3*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB floats.  x1 is read only when first != 0. */
+ * slab: grid_rows*(3*MSST_MLP_SLAB + MSST_LN1_SLAB) + nchunk*heads*MSST_ATTN_SLAB floats.  x1 is read only when first != 0.
+ * tile_queue != NULL (data parallel): the attention backward and the fused LN1 + MLP launch draw their tiles from agent-scope
+ * counters in this scratch (zeroed on `stream` by the call) instead of the static partition tile = workgroup + k * grid: a
+ * workgroup that starts late because a communication kernel holds its CU draws fewer tiles instead of running its whole
+ * share behind the others.  The partition then depends on timing, so the gradients differ from run to run in fp32 summation
+ * order; NULL keeps the static, bit-reproducible partition (the single-GPU default). */
+#define MSST_TILE_QUEUE_WORDS 64
 int msst_block_bwd_chain(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /*host*/,
                          const MsstBlockWeights* w_prev /*host, block i - 1 or NULL*/, const MsstBlockGrads* g_prev /*host*/,
                          const float* x, const float* x1, const float* x1_prev, const float* dy, float* dx, float* dx1,
                          void* dxn_part, float* slab, int grid_rows, int nchunk, int mode, int B, int S, int N, int heads,
                          int prec, float dropout_p, uint32_t seed, int layer, const void* xn_saved, void* dab_ws,
-                         int first, void* stream);
+                         int first, int32_t* tile_queue /*optional, MSST_TILE_QUEUE_WORDS int32 of device scratch*/, void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.
  * slab: S * nchunk * (N*96 + 96*P + 4*96 + 32) floats + S*N*96 floats (position staging).

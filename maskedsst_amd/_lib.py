@@ -58,7 +58,7 @@ _SIGS = {
     "msst_block_bwd_chain": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), POINTER(MsstBlockWeights),
                                      POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P, _P,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P,
-                                     c_int, _P]),
+                                     c_int, _P, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, c_float,
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),

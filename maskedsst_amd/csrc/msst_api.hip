@@ -310,7 +310,8 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
                           const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
                           const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                           int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                          uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int chain, int first, hipStream_t st) {
+                          uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int chain, int first, int32_t* tile_queue,
+                          hipStream_t st) {
     if (!bw_ok(w) || (w_prev && !bw_ok(w_prev)) || !g || grid_rows < 1 || nchunk < 1)
         return fail(MSST_ERR_BADARG, "msst_block_bwd (null argument, or MsstBlockWeights of another header revision)");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
@@ -337,6 +338,11 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
     if (chain && (!fast_rows || (w_prev && (!g_prev || !x1_prev)) || (first && !dy) || (!w_prev && !dx)))
         return fail(MSST_ERR_BADARG, "msst_block_bwd_chain (bf16 with saved LN1 rows and the dab workspace only)");
     const bool run_mlp = !chain || first;
+    // dynamic tile queues (data parallel): counters [0, heads / 2) for the two-head attention backward, [32] for the fused launch
+    if (tile_queue) {
+        hipError_t e = hipMemsetAsync(tile_queue, 0, MSST_TILE_QUEUE_WORDS * sizeof(int32_t), st);
+        if (e != hipSuccess) return fail((int)e, "msst_block_bwd_chain(tile queue)");
+    }
     // 1. MLP half: dy -> dx1
     if (run_mlp) {
         MlpBwdArgs a;
@@ -351,6 +357,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         aa.w = bw; aa.x = x; aa.da = dx1; aa.dxn_part = dxn_part; aa.slab = slab_attn;
         aa.xn = fast_rows ? xn_saved : nullptr; aa.dab = fast_rows ? dab_ws : nullptr;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
+        aa.queue = (tile_queue && heads / 2 <= 32) ? tile_queue : nullptr;
         aa.dbg = dbg & ~8;
         aa.stamps = nullptr;
 #ifdef MSST_STAMPS
@@ -372,6 +379,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
 #ifdef MSST_STAMPS
         a.stamps = g_stamps;
 #endif
+        a.queue = tile_queue ? tile_queue + 32 : nullptr;
         int rc = launch_block_bwd_ln1mlp(a, grid, st);
         if (rc) return fail(rc, "msst_block_bwd_chain(ln1 + mlp)");
     } else {
@@ -423,16 +431,16 @@ int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const flo
                    int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
                    uint32_t seed, int layer, const void* xn_saved, void* dab_ws, void* stream) {
     return block_bwd_impl(w, g, nullptr, nullptr, x, x1, nullptr, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
-                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 0, 0, (hipStream_t)stream);
+                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 int msst_block_bwd_chain(const MsstBlockWeights* w, const MsstBlockGrads* g, const MsstBlockWeights* w_prev,
                          const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
                          const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                          int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                         uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int first, void* stream) {
+                         uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int first, int32_t* tile_queue, void* stream) {
     return block_bwd_impl(w, g, w_prev, g_prev, x, x1, x1_prev, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
-                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 1, first, (hipStream_t)stream);
+                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 1, first, tile_queue, (hipStream_t)stream);
 }
 
 int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,

@@ -70,7 +70,7 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr int R4_ROWBUF = 24576, R4_DA = 12288;
 constexpr int R4_G0 = 49152, R4_GSZ = 49152;
 constexpr int R3_Q = 0, R3_K = 8192, R3_DO = 16384, R3_V = 24576, R3_P = 32768, R3_DS = 40960;
-constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SEQ = 160000, R4_SEQO = 160272, R4_SMEM = 160272 + 272;   // row map [64], sequence bases [65] x 2
+constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SEQ = 160000, R4_SEQO = 160272, R4_QT = 160272 + 272, R4_SMEM = R4_QT + 16;   // row map [64], sequence bases [65] x 2, tile ring [4]
 
 // 16-byte slot s of row r lives at slot s ^ fz(r) (128-byte rows) / (s & ~3) | ((s & 3) ^ fz2(r)) (192-byte rows)
 __device__ __forceinline__ int fz(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 3) & 1); }
@@ -132,7 +132,13 @@ __device__ __forceinline__ int launder3(int v) {
 
 }  // namespace
 
-template <bool DROP>
+// QUEUE (data parallel, opt-in): the tiles of a head pair are not statically partitioned over its workgroups (tile = chunk +
+// k nchunk) but drawn from one agent-scope counter per head pair, so a workgroup that starts late -- its CU was held by a
+// communication kernel's channel -- simply draws fewer tiles instead of running its whole share BEHIND the others.  Wave O of head
+// A draws two walk steps ahead (the atomic's round trip hides under phases 2 and 3) and publishes the tile through a four-entry LDS
+// ring; both heads read the same sequence, head B half a tile later.  The partition then depends on timing: gradients are no
+// longer bit-reproducible from run to run (summation order), which is why the static form stays the single-GPU default.
+template <bool DROP, bool QUEUE>
 __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_char* const sm = (lds_char*)smem_raw;
@@ -215,7 +221,18 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         }
         table[sx] = base;
     };
-    if (wv == 3) { fill_seqbase(seqbase, blockIdx.x); if ((tid & 63) == 0) { seqbase[64] = -1; seqout[64] = -1; } }
+    int* const qt = reinterpret_cast<int*>(smem_raw + R4_QT);
+    int qpend = 0;   // (QUEUE, lane 0 of wave O of head A) the draw in flight
+    if (wv == 3) {
+        int t0 = (int)blockIdx.x;
+        if (QUEUE) {
+            int r = 0;
+            if ((tid & 63) == 0) { r = __hip_atomic_fetch_add(a.queue + blockIdx.y, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); qt[0] = r; qt[1] = r + 1; }
+            t0 = __builtin_amdgcn_readfirstlane(r);
+        }
+        fill_seqbase(seqbase, t0);
+        if ((tid & 63) == 0) { seqbase[64] = -1; seqout[64] = -1; }
+    }
     __syncthreads();
     unsigned rinv[3], rsx[3];
 #pragma unroll
@@ -278,7 +295,9 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     }
 
     int xb = 0;   // row buffer of the tile
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x, xb = R4_ROWBUF - xb) {
+    int ks = 0;   // walk step
+    for (int tile = QUEUE ? __builtin_amdgcn_readfirstlane(qt[0]) : (int)blockIdx.x; tile < a.ntiles;
+         xb = R4_ROWBUF - xb, ++ks, tile = QUEUE ? __builtin_amdgcn_readfirstlane(qt[ks & 3]) : tile + (int)gridDim.x) {
         const int p1_in = xb + p1_row, p3_x = p1_in;
 #if defined(MSST_STAMPS)
         // cycle stamps of lane 0 of every wave of workgroup (7, 1), a mid-walk tile: stamps[16 wave + i]
@@ -335,12 +354,15 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (!(MSST_B3_EXP & 1024) && grp && tile != (int)blockIdx.x) copy_out();
+        if (!(MSST_B3_EXP & 1024) && grp && ks != 0) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
         B4_PRIO(2);
-        if (wv == 3) fill_seqbase(seqbase, tile + (int)gridDim.x);   // (read by head A's row requests behind barrier B2)
+        if (wv == 3) {   // (read by head A's row requests behind barrier B2)
+            fill_seqbase(seqbase, QUEUE ? qt[(ks + 1) & 3] : tile + (int)gridDim.x);
+            if (QUEUE && (tid & 63) == 0) qpend = __hip_atomic_fetch_add(a.queue + blockIdx.y, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // walk step ks + 2
+        }
         if (wv == 7) fill_seqbase(seqout, tile);                        // (read by head B's copy-out of this tile, three barriers on)
         // ---------------- phase 2: wave <-> 16 query rows; S^T, softmax, P, dP^T, dS (16 x 16 x 32 MFMAs) ----------------
         {
@@ -598,6 +620,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             if (!(MSST_B3_EXP & 64)) wgrad();
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
             if (roleO) {
+                if (QUEUE && !grp && (tid & 63) == 0) qt[(ks + 2) & 3] = qpend;   // published by barrier B4; first read at the top of walk step ks + 1 (wave O: next tile's bases)
                 load_w1();   // the next tile's phase-1 weights
             } else {
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
@@ -642,7 +665,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     if (!grp) {
 #pragma unroll
         for (int i = 0; i < MSST_B4_LAG; ++i) lds_barrier();   // head A: the barriers head B is behind
-    } else if ((int)blockIdx.x < a.ntiles) {   // (a workgroup without a tile never filled seqout: nothing to copy out)
+    } else if (ks > 0) {   // (a workgroup without a tile never filled seqout: nothing to copy out)
         copy_out();
     }
 
@@ -669,16 +692,17 @@ int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st) {
     if (!a.xn || !a.dab || !a.w.wqkv32 || !a.w.woutT32 || !a.w.wqkvT32 || nchunk < 1 || nchunk > a.ntiles) return MSST_ERR_BADARG;
     if (a.ntok * 192 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit row offsets of the copy-out descriptor
     typedef void (*kern_t)(AttnBwdArgs);
-    const kern_t kerns[2] = {&block_bwd_attn_r4_kernel<false>, &block_bwd_attn_r4_kernel<true>};
+    const kern_t kerns[4] = {&block_bwd_attn_r4_kernel<false, false>, &block_bwd_attn_r4_kernel<true, false>,
+                             &block_bwd_attn_r4_kernel<false, true>, &block_bwd_attn_r4_kernel<true, true>};
     if (!attr_set) {
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, R4_SMEM);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    hipLaunchKernelGGL(kerns[a.drop.thr ? 1 : 0], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
+    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.queue ? 2 : 0)], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
     return (int)hipGetLastError();
 }
 

@@ -72,6 +72,7 @@ struct LmSmem {
     float out[64][LDF];      // dx1 of block i - 1 (fp32) of the tile the M waves just finished: the L waves copy it out as whole rows
     float gam1[96];          // ln1_g of block i
     float touch_pad[64];     // landing area of the L2-touch loads (never read)
+    int qt[8];               // (QUEUE) tile of walk step k at [k & 7]
     float lnp[256];          // ln2_g | ln2_b | b1 of block i - 1
     char wl[36 * 1024];      // [w1 12 | w2T 12 | w1T 12] fragments of 1 KB (block i - 1)
 };
@@ -85,7 +86,10 @@ __device__ __forceinline__ float oct_sum5(float v) {
 }  // namespace
 
 // NP: partial buffers the attention backward of block i wrote (one per head pair: heads / 2; or one per head)
-template <int NP, bool DROP>
+// QUEUE (data parallel, opt-in): tiles drawn from one agent-scope counter instead of the static partition tile = workgroup +
+// k grid, so that a workgroup whose CU is held by a communication kernel draws fewer tiles instead of running its whole share
+// behind the others (see msst_bwd4.hip).  L wave 0 draws five walk steps ahead and publishes through an eight-entry LDS ring.
+template <int NP, bool DROP, bool QUEUE>
 __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     typedef LmSmem SM;
     constexpr int KS = 32, LDX = SM::LDX, LDH = SM::LDH;
@@ -95,8 +99,21 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     const int ntiles = (int)((a.ntok + 63) / 64);
     const int G = (int)gridDim.x;
     // k-th tile of this workgroup's walk
-    const int nmine = (ntiles - 1 - (int)blockIdx.x) / G + 1;   // blockIdx.x < ntiles (launcher)
-    auto tile_at = [&](int k) { return MSST_B5_REV ? (int)blockIdx.x + (nmine - 1 - k) * G : (int)blockIdx.x + k * G; };
+    const int nmine = (ntiles - 1 - (int)blockIdx.x) / G + 1;   // static partition: blockIdx.x < ntiles (launcher)
+    // tile of walk step k (static: valid for k < nmine; queue: any value >= ntiles ends the walk)
+    auto tile_at = [&](int k) -> int {
+        if (QUEUE) return sm.qt[k & 7];
+        return MSST_B5_REV ? (int)blockIdx.x + (nmine - 1 - k) * G : (int)blockIdx.x + k * G;
+    };
+    auto valid_step = [&](int k) -> bool { return QUEUE ? sm.qt[k & 7] < ntiles : k < nmine; };
+    auto tile_of_draw = [&](int d) -> int { return d < ntiles ? (MSST_B5_REV ? ntiles - 1 - d : d) : 0x7fffffff; };
+    int qpend = 0;   // (QUEUE, lane 0 of L wave 0) the draw in flight
+    if (QUEUE && tid == 256) {
+        const int r = __hip_atomic_fetch_add(a.queue, 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // walk steps 0 .. 4
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sm.qt[i] = tile_of_draw(r + i);
+        qpend = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);           // walk step 5
+    }
 
     // ---- common prologue: block i - 1's small vectors and the three MLP weight matrices -> LDS ----
     if (tid < 96) { sm.lnp[tid] = a.w.ln2_g[tid]; sm.lnp[96 + tid] = a.w.ln2_b[tid]; if (tid < 64) sm.lnp[192 + tid] = a.w.b1[tid]; }
@@ -117,6 +134,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         }
         wait_vm0();
     }
+    if (QUEUE) __syncthreads();   // the first five tiles are in the ring
 
     if (wave >= 4) {
         // =====================================================================================================
@@ -138,12 +156,13 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(parts), 0, 0x7fffffff, 0x00020000);
         const int pstride = (int)(a.ntok * 192);   // bytes between partial buffers (launcher: nparts * ntok * 192 < 2^31)
         auto issue = [&](int k, int ps0, int ps1) {
-            const int tile_ = (MSST_B5_EXP & 1) ? (int)blockIdx.x : tile_at(k < nmine ? k : nmine - 1);
+            const bool live = valid_step(k);
+            const int tile_ = (MSST_B5_EXP & 1) ? (int)blockIdx.x : live ? tile_at(k) : 0;
 #pragma unroll
             for (int ps = ps0; ps < ps1; ++ps) {
                 const int tok = tile_ * 64 + lw * 16 + ps * 8 + r8;
                 // requested unconditionally (a definition on every path), masked at use; past the end of the walk every lane asks for row 0
-                const int tokc = (tok < (int)a.ntok && k < nmine) ? tok : 0;
+                const int tokc = (tok < (int)a.ntok && live) ? tok : 0;
                 const int vo1 = tokc * 384 + 32 * p, vo2 = tokc * 384 + 256 + 16 * p;
                 const int vp1 = tokc * 192 + 16 * p, vp2 = tokc * 192 + 128 + 8 * p;
                 xq[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo1, 0, 0));
@@ -158,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
                     pb[ps][k2] = __builtin_amdgcn_raw_buffer_load_b64(rs_p, vp2, k2 * pstride, 0);
                 }
             }
-            if (MSST_B5_TOUCH && k < nmine && ps0 == 0) {
+            if (MSST_B5_TOUCH && live && ps0 == 0) {
                 // 64 rows x 384 B of x1 = 192 lines of 128 B: lanes 0..47 of each L wave take one line each
                 const long line = (long)tile_ * 192 + lw * 48 + (l < 48 ? l : 47);
                 const long last = (a.ntok * 384 - 1) >> 7;
@@ -274,14 +293,19 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         compute(0, 0, 2);
         issue(1, 0, 2);
         __syncthreads();
-        for (int k = 0; k < nmine; ++k) {
+        for (int k = 0; valid_step(k); ++k) {
+            // the draw issued a step ago (walk step k + 5) is published here, visible behind B1; the next one goes out
+            if (QUEUE && lw == 0 && l == 0) {
+                sm.qt[(k + 5) & 7] = tile_of_draw(qpend);
+                qpend = __hip_atomic_fetch_add(a.queue, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
             // M waves: walk step k (they read sm.dxf[k & 1] before B1).  Here: dx of step k + 1 into the other buffer, then the
             // rows of step k + 2 are requested -- a whole tile period ahead of their use
 #ifdef MSST_STAMPS
             const bool stamp_on = a.stamps && blockIdx.x == 100 && l == 0 && k == nmine / 2;
 #endif
             B5_STAMP(0);
-            if (k + 1 < nmine) {
+            if (valid_step(k + 1)) {
 #if MSST_B5_PASSPIPE
                 // pass by pass: the registers of a pass are re-requested (walk step k + 2) as soon as it is consumed, so that
                 // something is in flight all the time (all 28 requests behind the whole computation left the memory pipe idle half the tile)
@@ -343,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     };
     f32x4 xrow[6];
     auto request_rows = [&](int k) {
-        const int tile_ = tile_at(k < nmine ? k : nmine - 1);
+        const int tile_ = valid_step(k) ? tile_at(k) : 0;
         const long t_ = (long)tile_ * 64 + wave * 16 + c;
         const long tokc = t_ < a.ntok ? t_ : 0;
         const float* xs = a.x1 + tokc * 96 + 4 * g;
@@ -353,7 +377,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     request_rows(0);
     __syncthreads();
     if (MSST_B5_PRIO) __builtin_amdgcn_s_setprio(1);
-    for (int k = 0; k < nmine; ++k) {
+    for (int k = 0; valid_step(k); ++k) {
         const int tile = tile_at(k);
         const long tok = (long)tile * 64 + wave * 16 + c;
         const bool valid = tok < a.ntok;
@@ -555,14 +579,18 @@ int launch_block_bwd_ln1mlp(const LnMlpArgs& a, int grid, hipStream_t st) {
     if (grid > ntiles) grid = ntiles;
 #define MSST_B5_FOR_ALL(X) X(1, false) X(1, true) X(2, false) X(2, true) X(3, false) X(3, true) X(4, false) X(4, true)
     if (!attr_set) {
-#define MSST_B5_ATTR(np, dr) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr>), \
+#define MSST_B5_ATTR(np, dr) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, false>), \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; \
+                               e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, true>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; }
         MSST_B5_FOR_ALL(MSST_B5_ATTR)
         attr_set = true;
     }
     ProfScope ps(K_BWD_LN1MLP, st);
     const bool dr = a.drop_i.thr != 0 || a.drop_p.thr != 0;
-#define MSST_B5_LAUNCH(np, drv) if (a.nparts == np && dr == drv) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv>), dim3(grid), dim3(512), smem, st, a);
+#define MSST_B5_LAUNCH(np, drv) if (a.nparts == np && dr == drv) { \
+        if (a.queue) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, true>), dim3(grid), dim3(512), smem, st, a); \
+        else hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, false>), dim3(grid), dim3(512), smem, st, a); }
     MSST_B5_FOR_ALL(MSST_B5_LAUNCH)
     return (int)hipGetLastError();
 }

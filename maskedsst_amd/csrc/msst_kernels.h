@@ -98,6 +98,7 @@ struct AttnBwdArgs {
     int dbg;
     unsigned long long* stamps;
     Drop drop;
+    int* queue;       // optional (two-head kernel): one zeroed counter per head pair -> dynamic tile queue instead of the static partition
 };
 
 struct Ln1BwdArgs {
@@ -122,6 +123,7 @@ struct LnMlpArgs {
     int nparts;
     Drop drop_i, drop_p;     // dropout streams of block i (site 2) and of block i - 1 (sites 2, 3, 4)
     unsigned long long* stamps;   // -DMSST_STAMPS builds: cycle stamps of the eight waves of one workgroup (tools/stamps_bwd5.py)
+    int* queue;                   // optional: one zeroed counter -> dynamic tile queue instead of the static partition
 };
 
 struct TokBwdArgs {

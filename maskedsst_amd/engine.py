@@ -59,6 +59,7 @@ class Engine:
             (self.default_attn_chunks() if torch.cuda.is_available() else 64)
         self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "64"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
+        self.tile_queue = False  # data parallel: the backward's persistent grids draw tiles from a queue (no static partition)
         self._wbuf = None
         self._jobs = None
         self._bw = None
@@ -317,6 +318,12 @@ class Engine:
                  and nparts <= 4 and os.environ.get("MSST_BWD_CHAIN", "1") != "0" and len(layers) > 0
                  and ntok * 384 < 2 ** 31 - 16 and nparts * ntok * 192 < 2 ** 31 - 16)   # 32-bit buffer offsets in the fused launch
         if chain:
+            # dynamic tile queues (attach_data_parallel sets self.tile_queue; MSST_TILE_QUEUE=1 forces them): see include/msst.h
+            queue = None
+            if self.tile_queue or os.environ.get("MSST_TILE_QUEUE", "0") == "1":
+                if getattr(self, "_queue_ws", None) is None or self._queue_ws.device != dev:
+                    self._queue_ws = torch.zeros(64, dtype=torch.int32, device=dev)
+                queue = self._queue_ws
             last = len(layers) - 1
             dx0 = torch.empty_like(dy)
             null_w = ctypes.POINTER(MsstBlockWeights)()
@@ -330,7 +337,7 @@ class Engine:
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
                     _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec, drop[0], drop[1], i, _p(xns[i]), _p(dab), 1 if i == last else 0, _stream()),
+                    B, S, N, H, self.prec, drop[0], drop[1], i, _p(xns[i]), _p(dab), 1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
                 self._fire(f"{sname}.{l}")
             return dx0

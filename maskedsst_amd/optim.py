@@ -209,6 +209,14 @@ def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
     # 8, 16 or 32 probes on the full grids; with 16 CUs left free 28.1 ms (+6 %) for 8 / 16 probes but 34.7 ms (+31 %) for 32;
     # with 32 CUs left free 27.6-27.7 ms (+4.5 %) for all three.  Hence 32 (RCCL's default channel count on this node is below
     # that); the r04 sweep (profiles/r04_dp_cu_contention.jsonl) adds the no-probe run on the reserved grids.
+    # Round 4: under data parallel the attention backward and the fused LN1 + MLP launch no longer partition their tiles
+    # statically but DRAW them (engine.tile_queue -> msst_block_bwd_chain's tile_queue): a workgroup whose CU is held by a
+    # channel workgroup simply draws fewer tiles, so nothing has to be reserved (MSST_DP_RESERVE_CUS, default 0 now; the static
+    # partition with 32 reserved CUs is MSST_DP_TILE_QUEUE=0 MSST_DP_RESERVE_CUS=32).  Cost: the gradients are no longer
+    # bit-reproducible from run to run (fp32 summation order follows the draw order).
     if model.dp_world > 1 or os.environ.get("MSST_FORCE_DP", "0") == "1":
-        eng.reserve_cus(int(os.environ.get("MSST_DP_RESERVE_CUS", "32")))
+        eng.tile_queue = os.environ.get("MSST_DP_TILE_QUEUE", "1") != "0"
+        reserve = int(os.environ.get("MSST_DP_RESERVE_CUS", "0" if eng.tile_queue else "32"))
+        if reserve > 0:
+            eng.reserve_cus(reserve)
     return red

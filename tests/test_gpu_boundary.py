@@ -150,6 +150,61 @@ def test_cu_thief_probe_does_not_change_results():
     l2, g2 = grads()
     eng.attn_chunks, eng.grid_rows = chunks, rows
     assert l2 == l0 and rel_l2(g2, g0) < 1e-5       # another partition of the tiles: same sums, other summation order
+    # dynamic tile queue (what attach_data_parallel selects since round 4): the workgroups of the attention backward and of the
+    # fused LN1 + MLP launch DRAW their tiles; the partition depends on timing -- with and without the probe the same sums in
+    # another summation order (a last-bit difference in dx flips a bf16 rounding now and then: same bars as the chained-vs-
+    # unchained test), and the loss (forward only) is untouched
+    eng.tile_queue = True
+    l3, g3 = grads()
+    rc = eng.lib.msst_debug_cu_thief(32, 20000, ctypes.c_void_p(sink.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+    assert rc == 0
+    l4, g4 = grads()
+    side.synchronize()
+    eng.tile_queue = False
+    assert l3 == l0 and l4 == l0
+    for gq in (g3, g4):
+        assert torch.isfinite(gq).all()
+        worst = 0.0
+        for name, _p_ in eng.trainable():
+            b = eng.fp.view(name, g0)
+            if float(b.abs().max()) == 0.0:
+                continue
+            worst = max(worst, rel_l2(eng.fp.view(name, gq), b))
+        assert worst < 3.2e-3, worst
+
+
+def test_tile_queue_at_bench_batch(monkeypatch):
+    """The dynamic tile queue at BASELINE.json's batch (20 tiles per workgroup: the ring of drawn tiles wraps several times, head B
+    reads the sequence half a tile behind head A, the fused launch's L waves five steps ahead), one spatial and one spectral
+    block, against the static partition."""
+    cfg = dict(bands=200, depth=1, B=256)
+    model, _, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    drop = (0.1, 31)
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+
+    def run(q):
+        eng.tile_queue = q
+        eng.fp.grad.zero_()
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=drop)
+        torch.cuda.synchronize()
+        return dx0.clone(), eng.fp.grad.clone()
+
+    dx_s, g_s = run(False)
+    dx_q, g_q = run(True)
+    dx_q2, g_q2 = run(True)
+    eng.tile_queue = False
+    assert torch.isfinite(dx_q).all() and torch.isfinite(g_q).all()
+    assert rel_l2(dx_q, dx_s) < 5e-4 and rel_l2(dx_q2, dx_s) < 5e-4
+    worst = 0.0
+    for name, _p_ in eng.trainable():
+        b = eng.fp.view(name, g_s)
+        if float(b.abs().max()) == 0.0:
+            continue
+        worst = max(worst, rel_l2(eng.fp.view(name, g_q), b), rel_l2(eng.fp.view(name, g_q2), b))
+    assert worst < 3.2e-3, worst
 
 
 def test_transformer_forward_no_grad_matches_autograd_path():

@@ -138,7 +138,7 @@ def test_dp_wiring_single_rank_rccl(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-         "--master-port", str(port), str(script), forced], env={"MSST_FORCE_DP": "1", "MSST_DP_RESERVE_CUS": "0"})   # same grids as the plain run: bit-identical sums
+         "--master-port", str(port), str(script), forced], env={"MSST_FORCE_DP": "1", "MSST_DP_RESERVE_CUS": "0", "MSST_DP_TILE_QUEUE": "0"})   # same static grids as the plain run: bit-identical sums
     a, b = json.load(open(plain)), json.load(open(forced))
     assert a["rec"] == b["rec"], (a["rec"], b["rec"])
     assert a["p_sha"] == b["p_sha"]

@@ -41,9 +41,14 @@ timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profil
   python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null || true
 cut -c1-200 $OUT/bench_other_configs.jsonl
 # CU contention: the step with N occupancy-probe workgroups held on a side stream, default grid and the DP grid
+# static partition (single-GPU default), static partition on grids sized for 32 free CUs (round 3's DP choice; with and without a
+# probe), and the dynamic tile queue (round 4's DP choice: no reservation)
 ( python3 bench.py --no-cpu-baseline --no-pipeline --no-profile | tail -1
   for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done
-  for r in 16 32; do for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --thief-reserve $r | tail -1; done; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
+  python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief 1 --thief-us 1 --thief-reserve 32 | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --thief-reserve 32 | tail -1; done
+  python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --tile-queue | tail -1
+  for n in 8 16 32 48; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --tile-queue | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
 python3 - << 'PY'
 import json
 for l in open("gpurun_out/final/cu_contention.jsonl"):

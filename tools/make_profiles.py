@@ -19,15 +19,20 @@ def pmc(path, counter):
 
 fetch = pmc(os.path.join(SRC, "pmc_fetch.txt"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write.txt"), "WRITE_SIZE")
-short = {"block_fwd_hw_kernel": "block_fwd", "block_bwd_attn": "block_bwd_attn", "block_bwd_ln1": "block_bwd_ln1",
-         "block_bwd_mlp": "block_bwd_mlp", "tokenize_bwd": "tokenize_bwd", "tokenize_fwd": "tokenize_fwd",
-         "head_bwd": "head_bwd", "reduce_segs": "reduce_slabs", "adamw_kernel": "adamw", "head_fwd": "head_fwd"}
+# (pattern, bench.py kernel name): first match wins, the more specific pattern first
+short = [("block_fwd_rs_kernel", "block_fwd"), ("block_fwd_hw_kernel", "block_fwd"), ("block_bwd_attn", "block_bwd_attn"),
+         ("block_bwd_ln1mlp", "block_bwd_ln1mlp"), ("block_bwd_ln1", "block_bwd_ln1"),
+         ("block_bwd_mlp", "block_bwd_mlp"), ("tokenize_bwd", "tokenize_bwd"), ("tokenize_fwd", "tokenize_fwd"),
+         ("head_bwd", "head_bwd"), ("reduce_segs", "reduce_slabs"), ("adamw_kernel", "adamw"), ("head_fwd", "head_fwd"),
+         ("prep_weights", "prep_weights")]
 kern = {}
 for full, f in fetch.items():
-    for pat, s in short.items():
+    for pat, s in short:
         if pat in full:
             w = write.get(full, 0.0)
-            kern[s] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+            if s not in kern:
+                kern[s] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_per_launch": int((2 * f + w) * 1024)}
+            break
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), bench.py --steps 1 --warmup 1 "
                      "--batch 256 (tools/final_prof.sh), final kernels of the round",
            "correction": "FETCH_SIZE x2 (gfx950 16B/lane streaming under-report, MI355X_MICROARCH.md), WRITE_SIZE x1; KB -> bytes",
