@@ -29,6 +29,32 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
     if (sizeof(E) == 2 && j.pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) return;
     const int n = j.rows * j.cols;
     E* dst = reinterpret_cast<E*>(j.dst);
+    if constexpr (sizeof(E) == 2) {
+        // bf16: a thread writes the 8 consecutive k of one lane of one fragment -- 16 bytes of the fragment-packed destination
+        // (see PBF16::ld_w; round 4: one 16-byte store instead of eight 2-byte ones, 55 -> see DESIGN us for the launch)
+        const int R = j.transpose ? j.cols : j.rows, K = j.transpose ? j.rows : j.cols;   // logical [R][K] destination
+        if ((K & 7) == 0) {
+            const int RB = j.pack ? 32 : 16, KB = j.pack ? 16 : 32;   // fragment = RB rows x KB k, lane = (k / 8) * RB + row
+            if ((R % RB) == 0 && (K % KB) == 0) {
+                for (int i8 = blockIdx.x * 256 + threadIdx.x; i8 < n / 8; i8 += gridDim.x * 256) {
+                    const int f = i8 / 64, lane = i8 - f * 64;
+                    const int fr = f / (K / KB), fk = f - fr * (K / KB);
+                    const int r = fr * RB + (lane % RB), c0 = fk * KB + (lane / RB) * 8;
+                    s16x8 o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const int c = c0 + e;
+                        const int src_i = j.transpose ? c * j.cols + r : r * j.cols + c;   // dst[r][c] = src[c][r] when transposed
+                        float v = j.src[src_i];
+                        if (src_i / j.cols < j.scale_rows) v *= j.scale;
+                        o[e] = (short)f2bf(v);
+                    }
+                    *reinterpret_cast<s16x8*>(dst + (long)i8 * 8) = o;
+                }
+                return;
+            }
+        }
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
         // i indexes the destination (coalesced writes)
         int src_i = i;

@@ -75,6 +75,161 @@ __global__ __launch_bounds__(384) void head_bwd_kernel(HeadBwdArgs a) {
     if (tid < P) slab[P * 96 + tid] = accB;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// The same head backward for the reference's shapes (P = 10, N = 64) on the fp32 matrix cores (round 4).  The kernel above reads
+// its gathered gradient rows from LDS once per multiply-add (ten broadcast reads per row and thread), moves y / dy as scalars
+// and walks the CSR lists (three dependent loads) at the top of every sample: 131 us for 266 MB.  Here
+//   * wave w <-> tokens 16 w .. + 15 of spectral block c, persistent over the samples of its chunk;
+//   * the CSR walk of sample k + 3 / k + 2 / k + 1 (list bounds / first position / gradient values) is in flight while sample k
+//     is computed: each stage's request is one iteration old when its result is needed;
+//   * dy[token][d] = sum_p g[token][p] W[p][d]: 18 MFMAs (W^T as A operand, 18 registers for the whole walk; the gathered g is
+//     the B operand in the lane that gathered it); dW[p][d] += sum_token g[token][p] y[token][d]: 24 MFMAs over the wave's 16
+//     tokens, both operands transposed through a wave-private LDS tile.
+// Slab layout as above.  grid (S, nchunk), 256 threads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void head_bwd_mfma_kernel(HeadBwdArgs a) {
+    constexpr int P = 10, N = 64;
+    __shared__ float y_raw[4 * 96 * 17];   // wave-private y[feature][token] tiles in the walk; the epilogue's reduction array afterwards
+    __shared__ float g_t[4][16][17];      // wave-private g[p][token]
+    float (*y_t)[96][17] = reinterpret_cast<float (*)[96][17]>(y_raw);
+    const int c = blockIdx.x, chunk = blockIdx.y, tid = threadIdx.x, w = tid >> 6, l = tid & 63, g = l >> 4, j = l & 15;
+    const int T = a.T, K = a.K, nb = (int)gridDim.y;
+    const int wc = a.per_block ? c : 0;
+    // A fragments of W^T: lane (i = l & 15, kq = l >> 4) holds W[p = 4 ks + kq][16 mt + i] (zero beyond p = 9)
+    float wf[6][3];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int pp = 4 * ks + g;
+            wf[mt][ks] = pp < P ? a.w_pix[((long)wc * P + pp) * 96 + 16 * mt + j] : 0.f;
+        }
+    const float gs = a.gout ? a.gscale * a.gout[0] : a.gscale;
+    const int n = 16 * w + j, t = c * N + n;
+    f32x4 dW[6];
+#pragma unroll
+    for (int mt = 0; mt < 6; ++mt) dW[mt] = zero4();
+    float accB[3] = {0.f, 0.f, 0.f};
+    // the three in-flight stages of the CSR walk (values of samples b + nb, b + 2 nb, b + 3 nb at the top of iteration b)
+    int e0_2 = 0, e1_2 = 0, e0_3 = 0, e1_3 = 0;   // list bounds of the sample two / three iterations ahead
+    int e0_1 = 0, e1_1 = 0, pos_1 = 0;             // bounds + first position of the next sample
+    int e0_0 = 0, e1_0 = 0;                         // bounds of the current sample
+    float gv[3] = {0.f, 0.f, 0.f};                 // gradient values (first list entry) of the current sample
+    f32x4 yrow[6];
+    auto load_bounds = [&](int b, int& e0, int& e1) {
+        const int bc = b < a.B ? b : a.B - 1;
+        e0 = a.csr_ptr[(long)bc * (T + 1) + t];
+        e1 = a.csr_ptr[(long)bc * (T + 1) + t + 1];
+    };
+    auto load_pos = [&](int b, int e0, int e1) -> int {
+        const int bc = b < a.B ? b : a.B - 1;
+        return a.csr_pos[(long)bc * K + (e1 > e0 ? e0 : 0)];
+    };
+    auto load_vals = [&](int b, int pos, float (&v)[3]) {
+        const int bc = b < a.B ? b : a.B - 1;
+        const float* src = a.dpred + ((long)bc * K + pos) * P;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { const int pp = 4 * ks + g; v[ks] = src[pp < P ? pp : 0]; }
+    };
+    auto request_y = [&](int b) {
+        const int bc = b < a.B ? b : a.B - 1;
+        const float* src = a.y + ((long)bc * T + t) * 96 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) yrow[mt] = *reinterpret_cast<const f32x4*>(src + 16 * mt);
+    };
+    // prologue: fill the pipeline for the first sample
+    const int b0 = chunk;
+    load_bounds(b0, e0_0, e1_0);
+    load_bounds(b0 + nb, e0_1, e1_1);
+    load_bounds(b0 + 2 * nb, e0_2, e1_2);
+    load_bounds(b0 + 3 * nb, e0_3, e1_3);
+    { const int p0 = load_pos(b0, e0_0, e1_0); load_vals(b0, p0, gv); }
+    pos_1 = load_pos(b0 + nb, e0_1, e1_1);
+    request_y(b0);
+    for (int b = b0; b < a.B; b += nb) {
+        int ll = threadIdx.x & 63;
+        asm volatile("" : "+v"(ll));
+        const int gl = ll >> 4, jl = ll & 15;
+        // ---- this sample's gathered gradient g[token][p = 4 ks + g] ----
+        float gg[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) gg[ks] = (e1_0 > e0_0 && 4 * ks + g < P) ? gv[ks] : 0.f;
+        for (int e = e0_0 + 1; e < e1_0; ++e) {   // duplicates (the reference's misaligned index slicing produces them): rare
+            const int pos = a.csr_pos[(long)b * K + e];
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) if (4 * ks + g < P) gg[ks] += a.dpred[((long)b * K + pos) * P + 4 * ks + g];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { gg[ks] *= gs; accB[ks] += gg[ks]; }
+        f32x4 yv[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) yv[mt] = yrow[mt];
+        // ---- advance the CSR pipeline: values of b + nb, position of b + 2 nb, bounds of b + 4 nb ----
+        load_vals(b + nb, pos_1, gv);
+        e0_0 = e0_1; e1_0 = e1_1;
+        pos_1 = load_pos(b + 2 * nb, e0_2, e1_2);
+        e0_1 = e0_2; e1_1 = e1_2;
+        e0_2 = e0_3; e1_2 = e1_3;
+        load_bounds(b + 4 * nb, e0_3, e1_3);
+        // ---- dy = W^T g on the matrix cores; y and g to the wave's LDS tile for the weight gradient ----
+        float* dst = a.dy + ((long)b * T + t) * 96 + 4 * g;
+        float* yt = &y_t[w][4 * gl][jl];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) {
+            f32x4 acc = zero4();
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[mt][ks], gg[ks], acc, 0, 0, 0);
+            *reinterpret_cast<f32x4*>(dst + 16 * mt) = acc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) yt[(16 * mt + r) * 17] = yv[mt][r];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) g_t[w][4 * ks + gl][jl] = gg[ks];
+        request_y(b + nb);
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // dW[p][d] += sum over the wave's 16 tokens: A[i = feature][kk = token], B[j = p][kk = token]
+        const float* ya = &y_t[w][jl][gl];
+        const float* ga = &g_t[w][jl][gl];
+#pragma unroll
+        for (int ts = 0; ts < 4; ++ts) {
+            const float bx = ga[4 * ts];
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt) dW[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[16 * mt * 17 + 4 * ts], bx, dW[mt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---------------- slab: dW[p][d] (C[i = feature 16 mt + 4 g + r][j = p]) summed over the four waves, db[p] ----------------
+    float* slab = a.slab + ((long)c * gridDim.y + chunk) * (P * 96 + P);
+    float* red = y_raw;   // [96][17]
+    __syncthreads();
+    for (int which = 0; which < 4; ++which) {
+        if (w == which) {
+#pragma unroll
+            for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* cell = red + (16 * mt + 4 * g + r) * 17 + j;
+                    *cell = which == 0 ? dW[mt][r] : *cell + dW[mt][r];
+                }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < P * 96; i += 256) { const int pp = i / 96, d = i - pp * 96; slab[i] = red[d * 17 + pp]; }
+    __syncthreads();
+    // db[p]: lane (j, g) holds the sums of p = 4 ks + g over its token's samples; sum over the 64 tokens
+    float* redb = y_raw;   // [64 tokens][16]
+#pragma unroll
+    for (int ks = 0; ks < 3; ++ks) redb[n * 16 + 4 * ks + g] = accB[ks];
+    __syncthreads();
+    if (tid < P) {
+        float sres = 0.f;
+        for (int rr = 0; rr < 64; ++rr) sres += redb[rr * 16 + tid];
+        slab[P * 96 + tid] = sres;
+    }
+}
+
 // ==========================================================================================
 // reduce_segs: deterministic reduction of per-workgroup partial-gradient slabs, all segments of one
 // backward stage in ONE launch.  A 256-thread block owns 32 (or, 16-byte path, 128) consecutive outputs of one
@@ -1627,7 +1782,8 @@ __global__ __launch_bounds__(256) void pos_split_kernel(const float* dpos /*[S][
 int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st) {
     if (a.P > 16 || a.N > 64) return MSST_ERR_UNSUPPORTED;
     ProfScope ps(K_HEAD_BWD, st);
-    hipLaunchKernelGGL(head_bwd_kernel, dim3(a.S, nchunk), dim3(384), 0, st, a);
+    if (a.P == 10 && a.N == 64) hipLaunchKernelGGL(head_bwd_mfma_kernel, dim3(a.S, nchunk), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(head_bwd_kernel, dim3(a.S, nchunk), dim3(384), 0, st, a);
     return (int)hipGetLastError();
 }
 
