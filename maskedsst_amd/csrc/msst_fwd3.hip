@@ -33,6 +33,9 @@
 #ifndef MSST_F3_RPRIO
 #define MSST_F3_RPRIO 1
 #endif
+#ifndef MSST_F3_BAND
+#define MSST_F3_BAND 1   // spectral blocks: skip the score tiles outside the band j - 1 .. j + 1 at compile time
+#endif
 #ifndef MSST_F3_KM
 #define MSST_F3_KM 0   // 1: the R waves hash the keep masks of the attention-probability dropout (64-bit row masks in LDS), the A waves only
                        // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
@@ -186,9 +189,17 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
             const int rs = 8 * (c >> 2) + (c & 3) + 4 * hi;   // 0..31
             voff[hi] = ((rs >> 4) * 3) * 1024 + (g * 16 + (rs & 15)) * 16;   // K = 96 -> 3 fragments per 16 rows
         }
-        int qlo[4];
+        // do the 16 queries of tile j only meet the key tiles {0,1} {0,1,2} {1,2,3} {2,3}?  (true for every L <= 21: a sequence
+        // that starts in tile j - 1 or j ends before tile j + 2 starts; wave uniform, tile invariant)
+        bool band = L < 64 && MSST_F3_BAND;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) qlo[j] = ((j * 16 + c) / L) * L;
+        for (int j = 0; j < 4; ++j) {
+            const int s_lo = (16 * j) / L, s_hi = min((16 * j + 15) / L, tm.TS - 1);
+            const int k_lo = s_lo * L, k_hi = (s_hi + 1) * L - 1;   // s_lo > s_hi: an all-padding query tile, anything goes
+            const unsigned allow = j == 0 ? 0x3u : j == 1 ? 0x7u : j == 2 ? 0xeu : 0xcu;
+            for (int t = 0; t < 4; ++t)
+                if (s_lo <= s_hi && 16 * t <= k_hi && 16 * t + 15 >= k_lo && !((allow >> t) & 1u)) band = false;
+        }
         constexpr int NR = MSST_F3_RING;
         static_assert(NR >= 2 && NR <= 9, "ring depth");
         frag ring[NR][2];
@@ -268,14 +279,22 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 // pack) is what it waits for; two independent query tiles in flight fill those slots.  O rows go to the round's
                 // half of the O tile. ----
                 const float cs = a.scale * 1.44269504088896340736f;
-#pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
+                // NM0 / NM1: key tiles (bit t = keys 16 t .. + 15) the two query tiles of the pass can see at all -- 0xf in the spatial
+                // blocks; in the spectral blocks (several short sequences per tile) every other 16 x 16 score tile is masked anyway and
+                // is skipped at COMPILE time (MFMAs, exps, dropout hashes, and the P V MFMAs of a fully skipped 32-key chunk): for the
+                // 20-token sequences of the EnMAP shape 10 of the 16 score tiles remain.  (A run-time test per tile breaks the pass
+                // into basic blocks and costs more than it saves -- msst_fwd2.hip's MSST_F2_SKIP, LABNOTES round 1.)
+                auto attn_pair = [&](auto jp_c, auto masked_c, auto nm0_c, auto nm1_c) {
+                    constexpr int jp = decltype(jp_c)::value;
+                    constexpr bool MASKED = decltype(masked_c)::value;
+                    constexpr unsigned NM[2] = {(unsigned)decltype(nm0_c)::value, (unsigned)decltype(nm1_c)::value};
                     f32x4 s[2][4];
                     f32x4 o[2][4];
 #pragma unroll
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
+                            if (!((NM[u] >> t) & 1u)) { s[u][t] = zero4(); continue; }
                             s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
                             s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);
                         }
@@ -285,7 +304,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                         asm volatile("" : "+v"(lq));
                         const int cq = lq & 15, sh0 = 4 * (lq >> 4);
                         float mx[2] = {-INFINITY, -INFINITY};
-                        if (L == 64) {
+                        if (!MASKED) {
 #pragma unroll
                             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -293,16 +312,17 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) mx[u] = fmaxf(mx[u], s[u][t][r]);
                         } else {
-                            // several short sequences per tile: keys outside the query's own sequence are masked.  The validity of a
-                            // key is one bit of the query row's 64-bit mask (LDS, tile invariant): a sign-extending 1-bit field extract
-                            // gives 0 / ~0 and v_bfi selects score or -inf -- two full-rate instructions per score and no lane masks
-                            // (as compares against [lo, hi) the 64 lane masks of a wave were hoisted into SGPR pairs and spilled)
+                            // keys outside the query's own sequence are masked.  The validity of a key is one bit of the query row's
+                            // 64-bit mask (LDS, tile invariant): a sign-extending 1-bit field extract gives 0 / ~0 and v_bfi selects
+                            // score or -inf -- two full-rate instructions per score and no lane masks (as compares against [lo, hi)
+                            // the 64 lane masks of a wave were hoisted into SGPR pairs and spilled)
 #pragma unroll
                             for (int u = 0; u < 2; ++u) {
                                 const unsigned long long vmq = sm.vm[(2 * jp + u) * 16 + cq];
                                 const int vlo = (int)(unsigned)vmq, vhi = (int)(unsigned)(vmq >> 32);
 #pragma unroll
-                                for (int t = 0; t < 4; ++t)
+                                for (int t = 0; t < 4; ++t) {
+                                    if (!((NM[u] >> t) & 1u)) continue;
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) {
                                         const int m = __builtin_amdgcn_sbfe(t < 2 ? vlo : vhi, 16 * (t & 1) + sh0 + r, 1);   // 0 or -1
@@ -310,6 +330,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                         s[u][t][r] = v;
                                         mx[u] = fmaxf(mx[u], v);
                                     }
+                                }
                             }
                         }
                         float mc[2], sum[2] = {0.f, 0.f}, inv[2];
@@ -319,15 +340,16 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
-                            for (int u = 0; u < 2; ++u)
+                            for (int u = 0; u < 2; ++u) {
+                                if (!((NM[u] >> t) & 1u)) continue;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], cs, -mc[u])); s[u][t][r] = e; sum[u] += e; }
+                            }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(colgroup_sum(sum[u]));   // the dropout scale rides on the normalisation
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            // site 1: the keep bits of this query row come from the R waves (they hash while this wave computes: 48 quarter-rate
-                            // multiplies per lane and head less on the critical wave); same masks as drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g)
+                            // site 1 (MSST_F3_KM: keep bits hashed by the R waves): same masks as drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g)
                             int klo = -1, khi = -1;
                             if (DROP && MSST_F3_KM) {
                                 const unsigned long long kmq = sm.km[k & 1][h][(2 * jp + u) * 16 + cq];
@@ -335,6 +357,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                             }
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
+                                if (!((NM[u] >> t) & 1u)) continue;
                                 s[u][t] = s[u][t] * inv[u];
                                 if (DROP && MSST_F3_KM) {
 #pragma unroll
@@ -351,8 +374,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                         const frag p0 = pack2f(s[u][0], s[u][1]), p1 = pack2f(s[u][2], s[u][3]);
 #pragma unroll
                         for (int dd = 0; dd < 4; ++dd) {
-                            o[u][dd] = P::mma(vA[dd][0], p0, zero4());       // C[i = gathered channel][j = query]
-                            o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
+                            o[u][dd] = zero4();
+                            if (NM[u] & 3u) o[u][dd] = P::mma(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
+                            if (NM[u] & 12u) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
                         }
                     }
                     // pack2(o[2u'], o[2u' + 1]) holds, in lane (c, g), the natural channels 32 u' + 8 g .. + 7 of query row 16 j + c
@@ -368,6 +392,18 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     F3_STAMP(2 + 5 * rd + 2 * jp);
                     lds_barrier();
                     F3_STAMP(3 + 5 * rd + 2 * jp);
+                };
+                typedef std::integral_constant<int, 0> I0;
+                typedef std::integral_constant<int, 1> I1;
+                if (L == 64) {
+                    attn_pair(I0{}, std::false_type{}, std::integral_constant<int, 0xf>{}, std::integral_constant<int, 0xf>{});
+                    attn_pair(I1{}, std::false_type{}, std::integral_constant<int, 0xf>{}, std::integral_constant<int, 0xf>{});
+                } else if (band) {   // every query tile j only meets key tiles j - 1 .. j + 1 (checked against the row map in the prologue)
+                    attn_pair(I0{}, std::true_type{}, std::integral_constant<int, 0x3>{}, std::integral_constant<int, 0x7>{});
+                    attn_pair(I1{}, std::true_type{}, std::integral_constant<int, 0xe>{}, std::integral_constant<int, 0xc>{});
+                } else {
+                    attn_pair(I0{}, std::true_type{}, std::integral_constant<int, 0xf>{}, std::integral_constant<int, 0xf>{});
+                    attn_pair(I1{}, std::true_type{}, std::integral_constant<int, 0xf>{}, std::integral_constant<int, 0xf>{});
                 }
             }
         }
