@@ -42,7 +42,8 @@
                        // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
 #endif
 #ifndef MSST_F3_EXP
-#define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic
+#define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic,
+                        // 8 = every q / k / v weight request reads the same two fragments, 16 = no q / k / v weight requests inside the walk at all
 #endif
 
 #ifdef MSST_STAMPS
@@ -104,7 +105,10 @@ __device__ __forceinline__ frag ld_w_gather3(const elem* w, int K, int row32, in
 
 // weight-fragment pair number pi of head h: 0..5 q, 6..11 k, 12..17 gathered v (see msst_fwd2.hip)
 __device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* wqkv, int H, int h, const int (&voff)[2]) {
-    if (pi < 12) {
+    if (MSST_F3_EXP & 8) {   // timing experiment: every request reads the same two (hot) fragments
+        out[0] = P::ld_w(wqkv, 96, 0, 0);
+        out[1] = P::ld_w(wqkv, 96, 16, 0);
+    } else if (pi < 12) {
         const int st = pi / 3, ks = pi % 3;
         const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
         out[0] = P::ld_w(wqkv, 96, r0, ks * 32);
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                     cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                     ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
