@@ -33,6 +33,9 @@
 #ifndef MSST_F3_RPRIO
 #define MSST_F3_RPRIO 1
 #endif
+#ifndef MSST_F3_PK
+#define MSST_F3_PK 0
+#endif
 #ifndef MSST_F3_BAND
 #define MSST_F3_BAND 1   // spectral blocks: skip the score tiles outside the band j - 1 .. j + 1 at compile time
 #endif
@@ -341,6 +344,29 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) mc[u] = colgroup_max(mx[u]) * cs;
                         // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e: one FMA + one v_exp per element
+#if MSST_F3_PK
+                        // two scores per instruction where the ISA has a packed form (v_pk_fma_f32 for the exponent, v_pk_add_f32 for the
+                        // running sums): the A wave is bound by the number of instructions in its dependent chain, not by a pipe
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+                        f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int u = 0; u < 2; ++u) {
+                                if (!((NM[u] >> t) & 1u)) continue;
+                                const f32x2 cs2 = {cs, cs}, nm2 = {-mc[u], -mc[u]};
+#pragma unroll
+                                for (int r2 = 0; r2 < 2; ++r2) {
+                                    const f32x2 x2 = {s[u][t][2 * r2], s[u][t][2 * r2 + 1]};
+                                    const f32x2 a2 = __builtin_elementwise_fma(x2, cs2, nm2);
+                                    f32x2 e2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
+                                    s[u][t][2 * r2] = e2[0]; s[u][t][2 * r2 + 1] = e2[1];
+                                    sum2[u] = sum2[u] + e2;
+                                }
+                            }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) sum[u] = sum2[u][0] + sum2[u][1];
+#else
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -349,6 +375,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], cs, -mc[u])); s[u][t][r] = e; sum[u] += e; }
                             }
+#endif
 #pragma unroll
                         for (int u = 0; u < 2; ++u) inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(colgroup_sum(sum[u]));   // the dropout scale rides on the normalisation
 #pragma unroll
