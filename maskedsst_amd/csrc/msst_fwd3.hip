@@ -15,11 +15,13 @@
 //     exchange), the same rows x hidden half mh of the first MLP GEMM and x output half mh of the second.
 // Four barriers per tile (the middle and the end of each round) are the only synchronisation: every cross-wave hand-over of
 // the R pipeline (LN2 statistics of the two feature halves, LN2 rows, GELU rows) is placed across one of them.
+// Measured: 293 -> 258 us per launch (B = 256, EnMAP shape).  What bounds it now is instruction issue per SIMD (MFMA passes +
+// 4-cycle VALU issues: 91 % of the wall cycles by the counters), not latency: see DESIGN.md section 5 / LABNOTES.md round 4.
 //
 //   interval   A waves (tile k)                 R waves
 //   q0         round 0: projections, j = 0, 1   out-projection K half 1 of tile k-1 (O of round 1), bias / dropout / +x -> x1,
 //                                               partial LN2 statistics
-//   q1         round 0: j = 2, 3                LN2 of tile k-1 -> XN2; Wout fragments of K half 0 requested
+//   q1         round 0: j = 2, 3                LN2 of tile k-1 -> XN2; the 24 Wout fragments of K half 0 requested
 //   q2         round 1: projections, j = 0, 1   out-projection K half 0 of tile k (O of round 0); MLP GEMM 1 + GELU of tile k-1
 //   q3         round 1: j = 2, 3                MLP GEMM 2 of tile k-1 -> y; LN1 of tile k+1 -> XN[(k+1) & 1]
 #include <atomic>
@@ -62,11 +64,6 @@ namespace {
 typedef PBF16 P;
 typedef bf16_t elem;
 typedef s16x8 frag;
-
-__device__ __forceinline__ float oct_sum3(float v) {   // (unused by the 4-threads-per-row LN1 below; kept for 8-thread variants)
-    v = quad_sum(v);
-    return v + __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xF, 0xF, true));
-}
 
 struct Fwd3Smem {
     static constexpr int LDX = 96 + 16;    // row stride = 2 mod 4 sixteen-byte slots: conflict-free b128 fragment reads
@@ -450,8 +447,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // =========================================================================================================
     const int rw = wv - 4, mh = rw & 1, rh = rw >> 1;
     const int rt = tid - 256;                   // 0..255: LN1 thread <-> (row rt / 4, 24 features 16 (i / 4) + 4 (rt % 4) + i % 4)
-    const elem* w1l = reinterpret_cast<const elem*>(sm.wmlp);
-    (void)w1l;
 
     // ---- LN1 of walk step k: x rows -> XN[k & 1] (+ the bf16 rows to HBM for the attention backward) ----
     f32x4 xv[6];   // this thread's 24 row values of the tile LN1 processes next (requested one interval ahead)
