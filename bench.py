@@ -165,9 +165,10 @@ def main():
     # warmup doubles as the survey pass: every kernel is timed there, the timed region then carries event
     # pairs only around the dominant MFMA kernel (the one the roofline object is about)
     lib.msst_profile_select(ctypes.c_ulonglong(~0 & (2 ** 64 - 1)))
-    if prof and args.warmup > 0:
-        lib.msst_profile_enable(1)
-    for _ in range(args.warmup):
+    for w in range(args.warmup):
+        if prof and w == args.warmup - 1:
+            torch.cuda.synchronize()
+            lib.msst_profile_enable(1)   # the survey is the LAST warmup step: the first ones carry cold caches and lazy initialisation
         step()
     torch.cuda.synchronize()
     survey = collect() if (prof and args.warmup > 0) else {}
