@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSST_VERSION 101
+#define MSST_VERSION 102
 #define MSST_DIM 96
 #define MSST_DIM_HEAD 64
 #define MSST_MLP 64
@@ -39,6 +39,7 @@ extern "C" {
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
 #define MSST_KERNEL_FWD_HW (256 << 8)    /* bf16 forward, 8 heads: the lockstep head-per-wave kernel (msst_fwd2.hip) instead of the role-split one (msst_fwd3.hip) */
+#define MSST_BWD_DEFER_REDUCE (512 << 8) /* msst_block_bwd_chain: leave the partial-gradient slabs of this call unreduced (msst_block_bwd_reduce does a run of calls in one launch) */
 #define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 
 #define MSST_MODE_SPATIAL 0  /* sequences = (b, c), N tokens each, contiguous            */
@@ -185,6 +186,19 @@ int msst_block_bwd_chain(const MsstBlockWeights* w /*host*/, const MsstBlockGrad
                          void* dxn_part, float* slab, int grid_rows, int nchunk, int mode, int B, int S, int N, int heads,
                          int prec, float dropout_p, uint32_t seed, int layer, const void* xn_saved, void* dab_ws,
                          int first, int32_t* tile_queue /*optional, MSST_TILE_QUEUE_WORDS int32 of device scratch*/, void* stream);
+
+/* Deferred slab reduction for a RUN of msst_block_bwd_chain calls made with MSST_BWD_DEFER_REDUCE in `prec`: one launch instead of
+ * one per block (the reduction is the only part of a block backward whose cost does not shrink with the problem: 62 MB of
+ * slabs per block at the bench grid, whatever the batch).  Call y = 0 .. count - 1 of the run used the workspace slab + y *
+ * slab_stride floats (same grid_rows / nchunk / mode / shapes for all of them) and reduced-gradient destinations that lie
+ * grad_stride floats apart: g + y * grad_stride for the attention half and LN1 of its block, g_prev + y * grad_stride for the
+ * MLP half of the block before it that its fused launch ran (the first count_prev calls of the run had one; count_prev = count
+ * except for the run that ends with block 0).  first != 0: call 0 of the run was made with first != 0 (standalone MLP half of
+ * its own block, reduced into g).  slab_stride and grad_stride must be multiples of 4 floats.  Deterministic: same
+ * summation order as the per-call reduction. */
+int msst_block_bwd_reduce(const MsstBlockGrads* g /*host*/, const MsstBlockGrads* g_prev /*host, may be NULL when count_prev == 0*/,
+                          float* slab, long slab_stride, long grad_stride, int count, int count_prev, int first,
+                          int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec, void* stream);
 
 /* Tokenizer backward: grads of blockwise_embed, pre/post norm, position table(s), mask token.
  * slab: S * nchunk * (N*96 + 96*P + 4*96 + 32) floats + S*N*96 floats (position staging).

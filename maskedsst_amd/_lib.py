@@ -40,6 +40,7 @@ class MsstBlockGrads(Structure):
 
 
 _P = c_void_p
+BWD_DEFER_REDUCE = 512 << 8   # include/msst.h: MSST_BWD_DEFER_REDUCE
 _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),
@@ -59,6 +60,8 @@ _SIGS = {
                                      POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P, _P,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P,
                                      c_int, _P, _P]),
+    "msst_block_bwd_reduce": (c_int, [POINTER(MsstBlockGrads), POINTER(MsstBlockGrads), _P, ctypes.c_long, ctypes.c_long,
+                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "msst_tokenize_bwd": (c_int, [_P] * 10 + [c_int] + [_P] * 8 + [c_int, _P, c_int, c_int, c_int, c_int, c_float,
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),

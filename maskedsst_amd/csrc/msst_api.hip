@@ -329,6 +329,66 @@ int msst_head_bwd(const float* y, const float* dpred, const int32_t* csr_ptr, co
     return fail(rc, "msst_head_bwd(reduce)");
 }
 
+// where the parts of one block backward keep their partial-gradient slabs inside the caller's `slab` workspace
+struct SlabLayout {
+    int grid, grid_mlp, nc;
+    float *mlp, *attn, *ln1, *mlp_prev;
+};
+static SlabLayout slab_layout(float* slab, long ntok, int grid_rows, int nchunk, int ntiles_attn, int heads, int prec) {
+    SlabLayout l;
+    const int ntiles_rows = (int)((ntok + 63) / 64);
+    l.grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;   // LN1 backward: HBM bound at one workgroup per CU
+    // the bf16 MLP backward is latency bound and fits two workgroups per CU: twice the persistent grid (and slabs)
+    const int gmlp2 = (prec == MSST_PREC_BF16 && PBF16::WAVES_BWD_MLP == 2) ? 2 * grid_rows : grid_rows;
+    l.grid_mlp = gmlp2 < ntiles_rows ? gmlp2 : ntiles_rows;
+    l.nc = nchunk < ntiles_attn ? nchunk : ntiles_attn;
+    l.mlp = slab;
+    l.attn = l.mlp + (long)l.grid_mlp * MSST_MLP_SLAB_N;
+    l.ln1 = l.attn + (long)l.nc * heads * MSST_ATTN_SLAB_N;
+    l.mlp_prev = l.ln1 + (long)l.grid * MSST_LN1_SLAB;
+    return l;
+}
+// the reduction table of one block backward (or, ny_* > 1, of a run of chained ones: see msst_block_bwd_reduce).
+// g_mlp: gradients the standalone MLP half wrote slabs for (null: it did not run); g_prev: the same for the fused launch's MLP half
+static int reduce_block_slabs(const SlabLayout& lay, int heads, const MsstBlockGrads* g, const MsstBlockGrads* g_mlp, int ny_mlp,
+                              const MsstBlockGrads* g_prev, int ny_prev, int ny, long src_ystride, long dst_ystride, hipStream_t st) {
+    RSegBuilder rb;
+    auto fresh = [&]() { rb = RSegBuilder(); rb.r.src_ystride = src_ystride; rb.r.dst_ystride = dst_ystride; };
+    fresh();
+    const long ms = MSST_MLP_SLAB_N;
+    bool ok = true;
+    auto add_mlp = [&](const float* sm_, int nslab, const MsstBlockGrads* gg, int nyy) {
+        ok = ok && rb.add(sm_, ms, nslab, gg->w1, 6144, 0, 0, nyy);
+        ok = ok && rb.add(sm_ + 6144, ms, nslab, gg->w2, 6144, 0, 0, nyy);
+        ok = ok && rb.add(sm_ + 12288, ms, nslab, gg->b1, 64, 0, 0, nyy);
+        ok = ok && rb.add(sm_ + 12288 + 64, ms, nslab, gg->b2, 96, 0, 0, nyy);
+        ok = ok && rb.add(sm_ + 12288 + 160, ms, nslab, gg->ln2_g, 96, 0, 0, nyy);
+        ok = ok && rb.add(sm_ + 12288 + 256, ms, nslab, gg->ln2_b, 96, 0, 0, nyy);
+    };
+    if (g_mlp) add_mlp(lay.mlp, lay.grid_mlp, g_mlp, ny_mlp);
+    if (g_prev) add_mlp(lay.mlp_prev, lay.grid, g_prev, ny_prev);
+    if (g) {
+        ok = ok && rb.add(lay.ln1, 288, lay.grid, g->ln1_g, 96, 0, 0, ny);
+        ok = ok && rb.add(lay.ln1 + 96, 288, lay.grid, g->ln1_b, 96, 0, 0, ny);
+        ok = ok && rb.add(lay.ln1 + 192, 288, lay.grid, g->bo, 96, 0, 0, ny);
+        const long as = (long)heads * MSST_ATTN_SLAB_N;
+        const int inner = heads * 64;
+        for (int h = 0; h < heads && ok; ++h) {
+            const float* sh = lay.attn + (long)h * MSST_ATTN_SLAB_N;
+            for (int which = 0; which < 3 && ok; ++which)
+                ok = rb.add(sh + which * 6144, as, lay.nc, g->wqkv + ((long)(which * heads + h) * 64) * 96, 6144, 0, 0, ny);
+            ok = ok && rb.add(sh + 3 * 6144, as, lay.nc, g->wout + h * 64, 6144, 64, inner, ny);
+            if (rb.r.nseg > MSST_MAX_RSEG - 4 && h + 1 < heads) {   // flush when the table is nearly full
+                int rc = launch_reduce_segs(rb.r, st);
+                if (rc) return rc;
+                fresh();
+            }
+        }
+    }
+    if (!ok) return MSST_ERR_UNSUPPORTED;
+    return launch_reduce_segs(rb.r, st);
+}
+
 // chain == 0: the three halves of ONE block (MLP half -> attention half -> LN1 backward), msst_block_bwd.
 // chain != 0: msst_block_bwd_chain (see include/msst.h): [MLP half of block i when `first`] -> attention half of block i ->
 //             LN1 backward of block i fused with the MLP half of block i - 1 (w_prev), or alone (block 0).
@@ -346,19 +406,15 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
     const long ntok = (long)B * S * N;
     const BlockWeights bw = to_bw(w);
     const Drop drop = make_drop(dropout_p, seed, layer);
-    const int ntiles_rows = (int)((ntok + 63) / 64);
-    const int grid = grid_rows < ntiles_rows ? grid_rows : ntiles_rows;   // LN1 backward: HBM bound at one workgroup per CU
-    // the bf16 MLP backward is latency bound and fits two workgroups per CU: twice the persistent grid (and slabs)
-    const int gmlp2 = (prec == MSST_PREC_BF16 && PBF16::WAVES_BWD_MLP == 2) ? 2 * grid_rows : grid_rows;
-    const int grid_mlp = gmlp2 < ntiles_rows ? gmlp2 : ntiles_rows;
-    float* slab_mlp = slab;
-    float* slab_attn = slab_mlp + (long)grid_mlp * MSST_MLP_SLAB_N;
     AttnBwdArgs aa;
     aa.tm = make_tilemap(mode, B, S, N);
     aa.ntiles = ntiles_of(aa.tm);
-    const int nc = nchunk < aa.ntiles ? nchunk : aa.ntiles;
-    float* slab_ln1 = slab_attn + (long)nc * heads * MSST_ATTN_SLAB_N;
-    float* slab_mlp_prev = slab_ln1 + (long)grid * MSST_LN1_SLAB;   // chain: the fused launch's MLP slabs (block i - 1), one per workgroup
+    const SlabLayout lay = slab_layout(slab, ntok, grid_rows, nchunk, aa.ntiles, heads, prec);
+    const int grid = lay.grid, grid_mlp = lay.grid_mlp, nc = lay.nc;
+    float* slab_mlp = lay.mlp;
+    float* slab_attn = lay.attn;
+    float* slab_ln1 = lay.ln1;
+    float* slab_mlp_prev = lay.mlp_prev;   // chain: the fused launch's MLP slabs (block i - 1), one per workgroup
     // saved LN1 rows + pre-dropped bf16 da rows: both or neither, and only for the tuned bf16 attention kernel
     const bool fast_rows = xn_saved && dab_ws && prec == MSST_PREC_BF16 && !(dbg & 16);
     if (chain && (!fast_rows || (w_prev && (!g_prev || !x1_prev)) || (first && !dy) || (!w_prev && !dx)))
@@ -414,39 +470,10 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         int rc = launch_block_bwd_ln1(a, grid, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(ln1)");
     }
-    // 4. one deterministic reduction of all partial-gradient slabs written above
-    {
-        RSegBuilder rb;
-        const long ms = MSST_MLP_SLAB_N;
-        bool ok = true;
-        auto add_mlp = [&](const float* sm_, int nslab, const MsstBlockGrads* gg) {
-            ok = ok && rb.add(sm_, ms, nslab, gg->w1, 6144);
-            ok = ok && rb.add(sm_ + 6144, ms, nslab, gg->w2, 6144);
-            ok = ok && rb.add(sm_ + 12288, ms, nslab, gg->b1, 64);
-            ok = ok && rb.add(sm_ + 12288 + 64, ms, nslab, gg->b2, 96);
-            ok = ok && rb.add(sm_ + 12288 + 160, ms, nslab, gg->ln2_g, 96);
-            ok = ok && rb.add(sm_ + 12288 + 256, ms, nslab, gg->ln2_b, 96);
-        };
-        if (run_mlp) add_mlp(slab_mlp, grid_mlp, g);
-        if (fused) add_mlp(slab_mlp_prev, grid, g_prev);
-        ok = ok && rb.add(slab_ln1, 288, grid, g->ln1_g, 96);
-        ok = ok && rb.add(slab_ln1 + 96, 288, grid, g->ln1_b, 96);
-        ok = ok && rb.add(slab_ln1 + 192, 288, grid, g->bo, 96);
-        const long as = (long)heads * MSST_ATTN_SLAB_N;
-        const int inner = heads * 64;
-        for (int h = 0; h < heads && ok; ++h) {
-            const float* sh = slab_attn + (long)h * MSST_ATTN_SLAB_N;
-            for (int which = 0; which < 3 && ok; ++which)
-                ok = rb.add(sh + which * 6144, as, nc, g->wqkv + ((long)(which * heads + h) * 64) * 96, 6144);
-            ok = ok && rb.add(sh + 3 * 6144, as, nc, g->wout + h * 64, 6144, 64, inner);
-            if (rb.r.nseg > MSST_MAX_RSEG - 4 && h + 1 < heads) {   // flush when the table is nearly full
-                int rc = launch_reduce_segs(rb.r, st);
-                if (rc) return fail(rc, "msst_block_bwd(reduce)");
-                rb = RSegBuilder();
-            }
-        }
-        if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd(reduce table)");
-        int rc = launch_reduce_segs(rb.r, st);
+    // 4. one deterministic reduction of all partial-gradient slabs written above -- unless the caller collects the slab sets of a
+    //    run of chained calls and reduces them in one launch (MSST_BWD_DEFER_REDUCE, msst_block_bwd_reduce)
+    if (!(chain && (dbg & 512))) {
+        int rc = reduce_block_slabs(lay, heads, g, run_mlp ? g : nullptr, 1, fused ? g_prev : nullptr, 1, 1, 0, 0, st);
         if (rc) return fail(rc, "msst_block_bwd(reduce)");
     }
     return 0;
@@ -467,6 +494,20 @@ int msst_block_bwd_chain(const MsstBlockWeights* w, const MsstBlockGrads* g, con
                          uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int first, int32_t* tile_queue, void* stream) {
     return block_bwd_impl(w, g, w_prev, g_prev, x, x1, x1_prev, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
                           heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 1, first, tile_queue, (hipStream_t)stream);
+}
+
+int msst_block_bwd_reduce(const MsstBlockGrads* g, const MsstBlockGrads* g_prev, float* slab, long slab_stride, long grad_stride,
+                          int count, int count_prev, int first, int grid_rows, int nchunk, int mode, int B, int S, int N, int heads,
+                          int prec, void* stream) {
+    if (!g || count < 1 || count_prev < 0 || count_prev > count || (count_prev && !g_prev) || !slab || grid_rows < 1 || nchunk < 1 ||
+        (count > 1 && ((slab_stride & 3) || (grad_stride & 3))))
+        return fail(MSST_ERR_BADARG, "msst_block_bwd_reduce");
+    prec &= 0xff;
+    const long ntok = (long)B * S * N;
+    const TileMap tm = make_tilemap(mode, B, S, N);
+    const SlabLayout lay = slab_layout(slab, ntok, grid_rows, nchunk, ntiles_of(tm), heads, prec);
+    return fail(reduce_block_slabs(lay, heads, g, first ? g : nullptr, 1, count_prev ? g_prev : nullptr, count_prev, count,
+                                   slab_stride, grad_stride, (hipStream_t)stream), "msst_block_bwd_reduce");
 }
 
 int msst_tokenize_bwd(const float* img, const float* pre_g, const float* pre_b, const float* w_emb,

@@ -239,7 +239,10 @@ __global__ __launch_bounds__(256) void reduce_segs_kernel(RSegs r) {
     __shared__ f32x4 part[8][33];
     int si = 0;
     while (si + 1 < r.nseg && (int)blockIdx.x >= r.s[si + 1].blk0) ++si;
-    const RSeg g = r.s[si];
+    RSeg g = r.s[si];
+    if ((int)blockIdx.y >= g.ny) return;   // (block uniform)
+    g.src += (long)blockIdx.y * r.src_ystride;
+    g.dst += (long)blockIdx.y * r.dst_ystride;
     const int io = threadIdx.x & 31, sg = threadIdx.x >> 5;
     if (g.vec4) {
         // 128 consecutive outputs per block, 4 per thread; the slab loop keeps four 16-byte requests in flight
@@ -1790,7 +1793,7 @@ int launch_head_bwd(const HeadBwdArgs& a, int nchunk, hipStream_t st) {
 int launch_reduce_segs(const RSegs& r, hipStream_t st) {
     if (r.nseg <= 0 || r.nblocks <= 0) return 0;
     ProfScope ps(K_REDUCE, st);
-    hipLaunchKernelGGL(reduce_segs_kernel, dim3(r.nblocks), dim3(256), 0, st, r);
+    hipLaunchKernelGGL(reduce_segs_kernel, dim3(r.nblocks, r.ny_max > 1 ? r.ny_max : 1), dim3(256), 0, st, r);
     return (int)hipGetLastError();
 }
 

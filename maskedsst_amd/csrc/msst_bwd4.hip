@@ -115,6 +115,21 @@ __device__ __forceinline__ s16x8 ld_w32(const void* w, int f, int lane16) {
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x7fffffff, 0x00020000);
     return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, f * 1024, 0));
 }
+// the same with the fragment offset split into a wave-uniform base (SGPR) and a small constant that rides in the instruction's 12-bit
+// offset field (< 4 KB: four fragments per base).  One SGPR per FOUR fragments instead of one per fragment: with twelve phase-1 and
+// twelve phase-4 fragment offsets precomputed, the register allocator parked two dozen of them in VGPR lanes and every request paid a
+// v_readlane + s_nop 4 to get its offset back (47 spilled SGPRs, ~50 reloads per tile).
+__device__ __forceinline__ s16x8 ld_w32b(const void* w, int base_bytes, int imm_bytes, int lane16) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16 + imm_bytes, base_bytes, 0));
+}
+__device__ __forceinline__ int launder_s(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
+}
+#ifndef MSST_B4_WBASE
+#define MSST_B4_WBASE 1   // weight fragment requests as base + immediate (0: one precomputed offset per fragment)
+#endif
 // 16 bytes per lane, global -> LDS without passing registers: lane i's bytes land at lds_dst + 16 i (lds_dst wave uniform, below
 // 64 KB); a lane whose offset lies outside the descriptor writes zeros.  Opaque to the compiler's vmcnt bookkeeping (the builtin
 // form makes every later LDS read wait for vmcnt(0)): loads return in order, so the compiler's own waits only become more
@@ -282,10 +297,15 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     s16x8 w1[2][6];
     auto load_w1 = [&]() {
         const int l16 = (launder3(tid) & 63) * 16;
+        const int b1 = launder_s(f1_0 * 1024);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 6; ++ks) w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
+            for (int ks = 0; ks < 6; ++ks) {
+                const int fi = 6 * dt + ks;
+                if (MSST_B4_WBASE && !(MSST_B3_EXP & 2)) w1[dt][ks] = ld_w32b(w1p, b1 + (fi >> 2) * 4096, (fi & 3) * 1024, l16);
+                else w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + fi, l16);
+            }
     };
     load_w1();
     lds_barrier();   // the first tile's rows are in row buffer 0
@@ -608,9 +628,14 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             const int l16 = l * 16;
             // (wave O, which has no phase 4, requests one hot fragment six times: a definition on every path keeps the register
             // allocator from shuffling the in-flight fragments of the other waves at the join)
+            // phase-4 fragment k12 = (which, ks): base of `which` (one SGPR each) + 1024 ks in the offset field
+            const int b4 = launder_s(roleO ? 0 : f4_0 * 1024), b4s = launder_s(roleO ? 0 : (inner >> 4) * 1024);
+            auto ld_w4 = [&](int k12) -> s16x8 {
+                if (MSST_B4_WBASE && !(MSST_B3_EXP & 1)) return ld_w32b(a.w.wqkvT32, b4 + (k12 >> 2) * b4s, (k12 & 3) * 1024, l16);
+                return ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
+            };
 #pragma unroll
-            for (int k12 = 0; k12 < MSST_B3_W4; ++k12)
-                w4[k12] = ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
+            for (int k12 = 0; k12 < MSST_B3_W4; ++k12) w4[k12] = ld_w4(k12);
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
@@ -636,8 +661,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     [&](int k12) {
                         c4[0] = mma32(w4[k12 % MSST_B3_W4], fb4[k12 % (MSST_B3_D4 + 1)][0], c4[0]);
                         c4[1] = mma32(w4[k12 % MSST_B3_W4], fb4[k12 % (MSST_B3_D4 + 1)][1], c4[1]);
-                        if (k12 + MSST_B3_W4 < 12)
-                            w4[k12 % MSST_B3_W4] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + MSST_B3_W4) >> 2) * (inner >> 4) + ((k12 + MSST_B3_W4) & 3), l16);
+                        if (k12 + MSST_B3_W4 < 12) w4[k12 % MSST_B3_W4] = ld_w4(k12 + MSST_B3_W4);
                         if (k12 == MSST_B3_W1AT) load_w1();   // the next tile's phase-1 weights, behind this phase's last weight request
                     });
                 // head A stages its rows; head B, two phases later, adds its own onto them (fp32 add of the bf16 values, one rounding)

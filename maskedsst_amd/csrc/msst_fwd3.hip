@@ -46,6 +46,17 @@
                        // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
                        // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
 #endif
+#ifndef MSST_F3_KMQ
+#define MSST_F3_KMQ 1   // (MSST_F3_KM) where the R waves hash: 1 = at the END of q0 / q2, at priority 0 -- the intervals whose barrier the R waves otherwise
+                        // sit out waiting for the A waves' projections; 0 = in q1 / q3 at the R waves' raised priority (the first version)
+#endif
+#ifndef MSST_F3_RPRIO02
+#define MSST_F3_RPRIO02 MSST_F3_RPRIO   // priority of the R waves in q0 / q2, where they finish early and wait for the A waves (q1 / q3, where the A waves wait for them: MSST_F3_RPRIO)
+#endif
+#ifndef MSST_F3_LN1Q
+#define MSST_F3_LN1Q 3   // interval in which the R waves run LN1 of tile k + 1: 3 = at the end of q3 (rows requested in q2), 2 = at the end of q2 (rows
+                         // requested at its start), the interval whose barrier the R waves otherwise sit out
+#endif
 #ifndef MSST_F3_EXP
 #define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic,
                         // 8 = every q / k / v weight request reads the same two fragments, 16 = no q / k / v weight requests inside the walk at all
@@ -103,11 +114,33 @@ __device__ __forceinline__ frag ld_w_gather3(const elem* w, int K, int row32, in
     return __builtin_bit_cast(frag, v);
 }
 
-// weight-fragment pair number pi of head h: 0..5 q, 6..11 k, 12..17 gathered v (see msst_fwd2.hip)
-__device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* wqkv, int H, int h, const int (&voff)[2]) {
+// weight-fragment pair number pi of head h: 0..5 q, 6..11 k, 12..17 gathered v (see msst_fwd2.hip).  Fragment f of the packed
+// [3 H 64][96] matrix starts at byte 1024 f; rows 16 i .. of block c (0 q, 1 k, 2 v) of head h are fragments ((c H + h) 4 + i) 3 + ks:
+// byte offset (c H + h) 12288 + 3072 i + 1024 ks.  hb = h * 12288 and HB = H * 12288 are wave-uniform values the caller keeps in two
+// SGPRs per round: one s_add per request instead of the five-instruction recomputation from h (MSST_F3_WOFF = 0: the first version).
+#ifndef MSST_F3_WOFF
+#define MSST_F3_WOFF 1
+#endif
+__device__ __forceinline__ frag ld_wb3(const elem* w, int voff, int soff) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(w), 0, 0x7fffffff, 0x00020000);
+    return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+__device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* wqkv, int H, int h, const int (&voff)[2], int hb, int HB, int l16) {
     if (MSST_F3_EXP & 8) {   // timing experiment: every request reads the same two (hot) fragments
         out[0] = P::ld_w(wqkv, 96, 0, 0);
         out[1] = P::ld_w(wqkv, 96, 16, 0);
+    } else if (MSST_F3_WOFF) {
+        if (pi < 12) {
+            const int st = pi / 3, ks = pi % 3;
+            const int o = hb + (st >> 1) * HB + (st & 1) * 6144 + ks * 1024;
+            out[0] = ld_wb3(wqkv, l16, o);
+            out[1] = ld_wb3(wqkv, l16, o + 3072);
+        } else {
+            const int mm = (pi - 12) / 3, ks = (pi - 12) % 3;
+            const int o = hb + 2 * HB + mm * 6144 + ks * 1024;
+            out[0] = ld_wb3(wqkv, voff[0], o);
+            out[1] = ld_wb3(wqkv, voff[1], o);
+        }
     } else if (pi < 12) {
         const int st = pi / 3, ks = pi % 3;
         const int r0 = ((st >> 1) * H + h) * 64 + (st & 1) * 32;
@@ -211,8 +244,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         // first pairs of the NEXT head of this wave (the other round's)
         // (pair p of a head always lives in slot p % NR: for pi >= 18 - NR the freed slots pi % NR run through 0 .. NR - 1 exactly once)
         auto next_pair = [](int pi) { return pi + NR < 18 ? pi + NR : pi % NR; };
+        const int HB = H * 12288, l16 = l * 16;
 #pragma unroll
-        for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wqkv, H, wv, voff);
+        for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wqkv, H, wv, voff, wv * 12288, HB, l16);
 
         __syncthreads();   // (P1) LN1 of the first tile is in XN[0]
         for (int k = 0; k < nmine; ++k) {
@@ -225,6 +259,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
             for (int rd = 0; rd < 2; ++rd) {
                 const int h = wv + 4 * rd;                  // this round's head
                 const int hn = wv + 4 * (1 - rd);           // the head whose first pairs follow in the weight stream
+                const int hb_c = sopaque3(h * 12288), hb_n = sopaque3(hn * 12288);   // (opaque per round: folded into 36 per-pair constants they would be hoisted out of the walk and spilled)
                 frag qB[4][2], kA[4][2], vA[4][2];
                 {
                     frag xf[4][3];   // LN1(x) as operand fragments: [16-row tile][k-step]
@@ -244,11 +279,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
+                                    if ((MSST_F3_EXP & 64) && t > 0) continue;   // (64: timing experiment, a quarter of the projection MFMAs)
                                     ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
                                     cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
@@ -265,11 +301,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
+                                    if ((MSST_F3_EXP & 64) && t > 0) continue;
                                     cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
                                     ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, sopaque3(pi + NR < 18 ? h : hn), voff);
+                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
@@ -300,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                         for (int t = 0; t < 4; ++t) {
                             if (!((NM[u] >> t) & 1u)) { s[u][t] = zero4(); continue; }
                             s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
-                            s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);
+                            if (!(MSST_F3_EXP & 128)) s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);   // (128: timing experiment, half the attention MFMAs)
                         }
                     if (!(MSST_F3_EXP & 4)) {
                         // bit position of key 16 t + 4 g + r inside its 32-bit half of a 64-bit row mask: 16 (t & 1) + 4 g + r
@@ -404,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                         for (int dd = 0; dd < 4; ++dd) {
                             o[u][dd] = zero4();
                             if (NM[u] & 3u) o[u][dd] = P::mma(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
-                            if (NM[u] & 12u) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
+                            if ((NM[u] & 12u) && !(MSST_F3_EXP & 128)) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
                         }
                     }
                     // pack2(o[2u'], o[2u' + 1]) holds, in lane (c, g), the natural channels 32 u' + 8 g .. + 7 of query row 16 j + c
@@ -673,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // keep masks of the attention-probability dropout of walk step k -> km[k & 1]: R lane rt hashes the 16 element groups of
     // (head, query row) = (2 part + rt / 128 ..., rt % 64): two rows per lane and tile, one per call (part = 0, 1)
     auto keep_masks = [&](int k, int part) {
-        if (!DROP || !MSST_F3_KM || k >= nmine) return;
+        if (!DROP || !MSST_F3_KM || k >= nmine || (MSST_F3_EXP & 32)) return;   // (32: timing experiment, masks left as they are)
         int rt = (int)threadIdx.x - 256;
         asm volatile("" : "+v"(rt));
         const int hq = part * 256 + rt, hh = hq >> 6, q = hq & 63;   // head 0..7, query row 0..63
@@ -708,13 +745,16 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #endif
         F3_STAMP(0);
         // ---------------- q0 ----------------
+        if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO02);
         if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); }
+        if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 0); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(2);
         lds_barrier();
         F3_STAMP(3);
         // ---------------- q1 ----------------
+        if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);
         if (have_prev) ln2();
-        keep_masks(k + 1, 0);
+        if (!MSST_F3_KMQ) keep_masks(k + 1, 0);
         if (rt < 64) fill_seq(k + 2, rt);   // (first read in q1 of the next step: LN1 request of step k + 2)
         if (have_cur) zero_acc();
         request_fw(0);
@@ -722,18 +762,23 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         lds_barrier();
         F3_STAMP(5);
         // ---------------- q2 ----------------
+        if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO02);
+        if (MSST_F3_LN1Q == 2 && k + 1 < nmine) request_ln1(k + 1);
         if (have_cur) outproj(0);
         F3_STAMP(6);
         if (have_prev) mlp1(k - 1);
-        if (k + 1 < nmine) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
+        if (MSST_F3_LN1Q == 2 && k + 1 < nmine) ln1(k + 1);
+        if (MSST_F3_LN1Q == 3 && k + 1 < nmine) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
+        if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 1); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(7);
         lds_barrier();
         F3_STAMP(8);
         // ---------------- q3 ----------------
+        if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);
         if (have_prev) mlp2(k - 1);
-        keep_masks(k + 1, 1);
+        if (!MSST_F3_KMQ) keep_masks(k + 1, 1);
         F3_STAMP(9);
-        if (k + 1 < nmine) ln1(k + 1);
+        if (MSST_F3_LN1Q == 3 && k + 1 < nmine) ln1(k + 1);
         request_fw(1);
         F3_STAMP(10);
         lds_barrier();

@@ -165,19 +165,26 @@ struct RSeg {
     const float* src; float* dst;
     long slab_stride;
     int nslab, n, row_len, row_stride, blk0, vec4;
+    int ny;   // batched launches (blockIdx.y = y): the segment exists for y < ny
 };
 #define MSST_MAX_RSEG 72
-struct RSegs { RSeg s[MSST_MAX_RSEG]; int nseg; int nblocks; };
+// A batched launch (ny_max > 1) reduces the same segment table for ny_max slab sets src_ystride floats apart into destinations
+// dst_ystride floats apart (the deferred reduction of a run of msst_block_bwd_chain calls: one slab set and one gradient block per call).
+struct RSegs { RSeg s[MSST_MAX_RSEG]; int nseg; int nblocks; int ny_max; long src_ystride, dst_ystride; };
 struct RSegBuilder {
     RSegs r;
-    RSegBuilder() { r.nseg = 0; r.nblocks = 0; }
-    bool add(const float* src, long slab_stride, int nslab, float* dst, int n, int row_len = 0, int row_stride = 0) {
+    RSegBuilder() { r.nseg = 0; r.nblocks = 0; r.ny_max = 1; r.src_ystride = 0; r.dst_ystride = 0; }
+    bool add(const float* src, long slab_stride, int nslab, float* dst, int n, int row_len = 0, int row_stride = 0, int ny = 1) {
         if (r.nseg >= MSST_MAX_RSEG) return false;
+        if (ny < 1) return true;   // a segment no launch of the batch wrote
         RSeg& g = r.s[r.nseg++];
+        g.ny = ny;
+        if (ny > r.ny_max) r.ny_max = ny;
         g.src = src; g.dst = dst; g.slab_stride = slab_stride; g.nslab = nslab; g.n = n;
         g.row_len = row_len > 0 ? row_len : n; g.row_stride = row_stride > 0 ? row_stride : n;
         g.blk0 = r.nblocks;
         // 16-byte path: a thread owns 4 consecutive outputs (one dwordx4 per slab) when every address involved is aligned
+        // (batched: the y strides must keep that alignment too -- checked by the caller that sets them)
         g.vec4 = (n % 4 == 0 && g.row_len % 4 == 0 && g.row_stride % 4 == 0 && slab_stride % 4 == 0 &&
                   ((uintptr_t)src % 16) == 0 && ((uintptr_t)dst % 16) == 0) ? 1 : 0;
         const int per_block = g.vec4 ? 128 : 32;
@@ -185,6 +192,7 @@ struct RSegBuilder {
         return true;
     }
 };
+static_assert(sizeof(RSegs) <= 4096, "RSegs travels as a kernel argument");
 int launch_reduce_segs(const RSegs& r, hipStream_t st);
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st);
 int launch_block_bwd_attn(const AttnBwdArgs& a, int nchunk, int prec, hipStream_t st, int* nparts);

@@ -293,6 +293,27 @@ class Engine:
         self._fire("head")
         return dy
 
+    def _grad_stride(self, nlayers):
+        """floats between the gradient tensors of consecutive backward calls (block i -> block i - 1), or None when the blocks'
+        gradients are not laid out a constant, 16-byte-aligned stride apart (msst_block_bwd_reduce needs that)"""
+        if nlayers < 2:
+            return None
+        fields = [n for n, _ in MsstBlockGrads._fields_]
+        d0 = None
+        for i in range(nlayers - 1, 0, -1):
+            for f in fields:
+                a, b = getattr(self._bg[i], f), getattr(self._bg[i - 1], f)
+                if a is None or b is None:
+                    return None
+                d = b - a
+                if d0 is None:
+                    d0 = d
+                if d != d0:
+                    return None
+        if d0 is None or d0 <= 0 or d0 % 16:
+            return None
+        return d0 // 4
+
     def blocks_bwd(self, acts, x1s, dy, drop=(0.0, 0)):
         """backward through the 2*depth blocks (reverse order); returns dx0"""
         B = dy.shape[0]
@@ -328,18 +349,43 @@ class Engine:
             dx0 = torch.empty_like(dy)
             null_w = ctypes.POINTER(MsstBlockWeights)()
             null_g = ctypes.POINTER(MsstBlockGrads)()
+            # Deferred slab reduction (msst_block_bwd_reduce, opt-in with MSST_BWD_DEFER=1): every call of a run of same-mode blocks
+            # keeps its own slab set and ONE launch reduces the run -- 2 block reductions per step instead of 2 * depth.  Bit-identical
+            # gradients; measured (LABNOTES round 4): the reductions drop from 566 to 400 us per EnMAP step, but the producers pay it
+            # back -- their slab epilogues now write 1.5 GB of cold memory per step instead of the same 62 MB that the reduction just
+            # read (attention backward +6 us per launch) -- so the per-call reduction stays the default.
+            gstride = self._grad_stride(len(layers))
+            defer = gstride is not None and os.environ.get("MSST_BWD_DEFER", "0") == "1"
+            nslab_r = (nslab + 3) // 4 * 4
+            if defer:
+                slab = torch.empty(nslab_r * len(layers), dtype=torch.float32, device=dev)
+            run_start = last
             for i in reversed(range(len(layers))):
                 sname, l = layers[i]
                 mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
                 prev = i > 0
+                y = last - i
+                slab_i = slab[y * nslab_r:] if defer else slab
                 _lib.check(self.lib.msst_block_bwd_chain(
                     ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]),
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
-                    _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec, drop[0], drop[1], i, _p(xns[i]), _p(dab), 1 if i == last else 0, _p(queue), _stream()),
+                    _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab_i), self.grid_rows, self.attn_chunks, mode,
+                    B, S, N, H, self.prec | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(dab),
+                    1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
-                self._fire(f"{sname}.{l}")
+                if not defer:
+                    self._fire(f"{sname}.{l}")
+                elif i == 0 or layers[i - 1][0] != sname:   # the run of this stack ends here: reduce it, then announce its blocks
+                    count = run_start - i + 1
+                    _lib.check(self.lib.msst_block_bwd_reduce(
+                        ctypes.byref(self._bg[run_start]), ctypes.byref(self._bg[run_start - 1]) if run_start > 0 else null_g,
+                        _p(slab[(last - run_start) * nslab_r:]), nslab_r, gstride, count, count if i > 0 else count - 1,
+                        1 if run_start == last else 0, self.grid_rows, self.attn_chunks, mode, B, S, N, H, self.prec, _stream()),
+                        "msst_block_bwd_reduce")
+                    for j in range(run_start, i - 1, -1):
+                        self._fire(f"{layers[j][0]}.{layers[j][1]}")
+                    run_start = i - 1
             return dx0
         g = dy
         other = torch.empty_like(dy)

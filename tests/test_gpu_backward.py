@@ -295,3 +295,47 @@ def test_chained_backward_matches_unchained(cfg, drop, monkeypatch):
     record("chained_backward_matches_unchained", cfg=cfg, drop=list(drop), dx=e_dx, worst_grad=worst)
     assert e_dx < 5e-4, e_dx
     assert not bad, bad
+
+
+DEFER_CASES = [
+    dict(bands=200, depth=2, B=5),
+    dict(bands=50, depth=3, B=4),                                # runs of three calls per stack
+    dict(bands=30, depth=2, B=3, heads=2, image_size=6, mask_patch_size=2),
+    dict(bands=50, depth=1, B=3, heads=4),                       # one call per run: the spectral run's fused MLP half belongs to the spatial block
+]
+
+
+@pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 777)], ids=["nodrop", "drop0.1"])
+@pytest.mark.parametrize("cfg", DEFER_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_deferred_slab_reduction_is_bit_identical(cfg, drop, monkeypatch):
+    """msst_block_bwd_reduce (one slab reduction per run of same-mode blocks: MSST_BWD_DEFER_REDUCE) against the reduction at
+    the end of every msst_block_bwd_chain call: the same slabs summed in the same order -- every gradient bit for bit, and the
+    hooks that announce finished blocks fire once per block in backward order either way."""
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+    assert eng._grad_stride(len(eng._layers())) is not None, "flat gradient layout is not a constant stride per block"
+
+    def run(defer):
+        monkeypatch.setenv("MSST_BWD_DEFER", defer)
+        eng.fp.grad.zero_()
+        fired = []
+        old = eng._fire
+        eng._fire = lambda name: fired.append(name)
+        try:
+            dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=drop)
+        finally:
+            eng._fire = old
+        torch.cuda.synchronize()
+        return dx0.clone(), eng.fp.grad.clone(), fired
+
+    dx_d, g_d, f_d = run("1")
+    dx_i, g_i, f_i = run("0")   # (the default)
+    monkeypatch.delenv("MSST_BWD_DEFER")
+    assert f_d == f_i and len(f_d) == len(eng._layers())
+    assert torch.equal(dx_d, dx_i)
+    assert float(g_d.abs().max()) > 0.0
+    bad = [name for name, p in eng.trainable() if not torch.equal(eng.fp.view(name, g_d), eng.fp.view(name, g_i))]
+    assert not bad, bad

@@ -194,7 +194,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
     loaded = _lib.load()
-    assert loaded.msst_version() == 101
+    assert loaded.msst_version() == 102
 
 
 def test_product_does_not_import_oracle():
