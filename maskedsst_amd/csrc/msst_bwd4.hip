@@ -680,7 +680,13 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, o, f2bf4(t4));
                     }
             }
-            if (!grp) wait_vm0();   // the next tile's rows are in LDS
+            // the next tile's rows are in LDS.  The twelve phase-1 weight fragments requested above are this wave's twelve YOUNGEST memory
+            // operations (head A: rows at barrier B2, then the phase-4 weights, then load_w1; requests return in order), so vmcnt(12) covers
+            // the rows without sitting out the weights' L2 round trip in front of barrier B4 (MSST_B4_VMW = 0: wait for everything)
+#ifndef MSST_B4_VMW
+#define MSST_B4_VMW 0    // (12 measured 526.9 / 527.4 vs 526.9 / 531.2 us: nothing to gain, and the count is an invariant to maintain)
+#endif
+            if (!grp) { if (MSST_B4_VMW == 12 && !(MSST_B3_EXP & 2)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vm0(); }
         }
         R4_STAMP(7);
         bar3();   // B4
