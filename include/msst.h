@@ -39,6 +39,10 @@ extern "C" {
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
 #define MSST_KERNEL_FWD_HW (256 << 8)    /* bf16 forward, 8 heads: the lockstep head-per-wave kernel (msst_fwd2.hip) instead of the role-split one (msst_fwd3.hip) */
+#define MSST_X1_BF16 (1024 << 8)         /* the saved mid-residual rows x1 are bf16 instead of fp32: msst_block_fwd writes them so (role-split bf16 forward only:
+                                            8 heads, no MSST_KERNEL_* flag; MSST_ERR_UNSUPPORTED otherwise), msst_block_bwd / _chain read x1 and x1_prev so (bf16
+                                            kernels only).  A quarter of the forward's writes and 8 % of the fused row-local backward's reads less; the LN2 statistics
+                                            of the backward are then those of the rounded rows (parity: tests/test_gpu_backward.py::test_bf16_x1_rows) */
 #define MSST_BWD_DEFER_REDUCE (512 << 8) /* msst_block_bwd_chain: leave the partial-gradient slabs of this call unreduced (msst_block_bwd_reduce does a run of calls in one launch) */
 #define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 

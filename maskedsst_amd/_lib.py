@@ -41,6 +41,7 @@ class MsstBlockGrads(Structure):
 
 _P = c_void_p
 BWD_DEFER_REDUCE = 512 << 8   # include/msst.h: MSST_BWD_DEFER_REDUCE
+X1_BF16 = 1024 << 8           # include/msst.h: MSST_X1_BF16
 _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),

@@ -282,6 +282,10 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.stamps = g_stamps;
     if (g_stamps) a.dbg = dbg;
 #endif
+    // MSST_X1_BF16: only the role-split forward (bf16, 8 heads, no kernel selection flags) writes bf16 x1 rows
+    a.x1_bf16 = (dbg & 1024) ? 1 : 0;
+    if (a.x1_bf16 && !(prec == MSST_PREC_BF16 && heads == 8 && !(dbg & (16 | 64 | 256))))
+        return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (MSST_X1_BF16 needs the role-split bf16 forward: 8 heads, no MSST_KERNEL_* flags)");
     a.drop = make_drop(dropout_p, seed, layer);
     a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
     if (xn_written) *xn_written = a.xn_out ? 1 : 0;
@@ -420,6 +424,10 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
     if (chain && (!fast_rows || (w_prev && (!g_prev || !x1_prev)) || (first && !dy) || (!w_prev && !dx)))
         return fail(MSST_ERR_BADARG, "msst_block_bwd_chain (bf16 with saved LN1 rows and the dab workspace only)");
     const bool run_mlp = !chain || first;
+    // MSST_X1_BF16: the saved mid-residual rows (x1, x1_prev) are bf16 -- the bf16 MLP-half kernels read either kind
+    const int x1b = (dbg & 1024) ? 1 : 0;
+    if (x1b && prec != MSST_PREC_BF16)
+        return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (MSST_X1_BF16 needs the bf16 kernels)");
     // dynamic tile queues (data parallel): counters [0, heads / 2) for the two-head attention backward, [32] for the fused launch
     if (tile_queue) {
         hipError_t e = hipMemsetAsync(tile_queue, 0, MSST_TILE_QUEUE_WORDS * sizeof(int32_t), st);
@@ -430,6 +438,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         MlpBwdArgs a;
         a.w = bw; a.x1 = x1; a.dy = dy; a.dx1 = dx1; a.slab = slab_mlp; a.ntok = ntok; a.drop = drop;
         a.dab = fast_rows ? dab_ws : nullptr;
+        a.x1_bf16 = x1b;
         int rc = launch_block_bwd_mlp(a, grid_mlp, prec, st);
         if (rc) return fail(rc, "msst_block_bwd(mlp)");
     }
@@ -455,6 +464,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         if (nparts > 4) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd_chain (more than four d(LN1 out) partials)");
         LnMlpArgs a;
         a.w = to_bw(w_prev); a.ln1_g = w->ln1_g; a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.x1 = x1_prev; a.dab = dab_ws;
+        a.x1_bf16 = x1b;
         a.slab_mlp = slab_mlp_prev; a.slab_ln1 = slab_ln1; a.ntok = ntok; a.nparts = nparts;
         a.drop_i = drop; a.drop_p = make_drop(dropout_p, seed, layer - 1);
         a.stamps = nullptr;

@@ -321,7 +321,7 @@ struct MlpBwdSmem {
     elem dhp[64][LDH];
 };
 
-template <class P>
+template <class P, bool X1B = false>
 __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(MlpBwdArgs a) {
     typedef typename P::elem elem;
     typedef typename P::frag frag;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
         const long tok0 = (long)blockIdx.x * 64 + wave * 16 + c;
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
-            xpre[mt] = tok0 < a.ntok ? *reinterpret_cast<const f32x4*>(a.x1 + tok0 * 96 + mt * 16 + 4 * g) : zero4();
+            xpre[mt] = tok0 < a.ntok ? ld_x1_4<X1B>(a.x1, tok0, mt * 16 + 4 * g) : zero4();
             dpre[mt] = tok0 < a.ntok ? *reinterpret_cast<const f32x4*>(a.dy + tok0 * 96 + mt * 16 + 4 * g) : zero4();
         }
     }
@@ -396,10 +396,9 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
     auto request_rows = [&](int tile_) {
         const long t_ = (long)tile_ * 64 + wave * 16 + c;
         const long tokc = (tile_ < ntiles && t_ < a.ntok) ? t_ : 0;
-        const float* xs = a.x1 + tokc * 96 + 4 * g;
         const float* ds_ = a.dy + tokc * 96 + 4 * g;
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) xrow[mt] = *reinterpret_cast<const f32x4*>(xs + mt * 16);
+        for (int mt = 0; mt < 6; ++mt) xrow[mt] = ld_x1_4<X1B>(a.x1, tokc, mt * 16 + 4 * g);
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) drow[mt] = *reinterpret_cast<const f32x4*>(ds_ + mt * 16);
     };
@@ -420,7 +419,7 @@ __global__ __launch_bounds__(256, P::WAVES_BWD_MLP) void block_bwd_mlp_kernel(Ml
                 xr = xpre[mt]; dr = dpre[mt];
                 const long tokn = tok + (long)gridDim.x * 64;   // same rows of this workgroup's next tile
                 const bool vn = tile + (int)gridDim.x < ntiles && tokn < a.ntok;
-                xpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.x1 + tokn * 96 + m0) : zero4();
+                xpre[mt] = vn ? ld_x1_4<X1B>(a.x1, tokn, m0) : zero4();
                 dpre[mt] = vn ? *reinterpret_cast<const f32x4*>(a.dy + tokn * 96 + m0) : zero4();
             } else {
                 xr = valid ? xrow[mt] : zero4();
@@ -1809,8 +1808,9 @@ static int set_smem(K kernel, size_t smem, std::atomic<bool>& done) {
 }
 
 int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st) {
-    static std::atomic<bool> d0{false}, d1{false};
+    static std::atomic<bool> d0{false}, d1{false}, d2{false};
     if (prec == MSST_PREC_F32) {
+        if (a.x1_bf16) return MSST_ERR_UNSUPPORTED;
         const size_t smem = sizeof(MlpBwdSmem<PF32>) + 256 * sizeof(float);
         int rc = set_smem(&block_bwd_mlp_kernel<PF32>, smem, d0);
         if (rc) return rc;
@@ -1818,10 +1818,12 @@ int launch_block_bwd_mlp(const MlpBwdArgs& a, int grid, int prec, hipStream_t st
         hipLaunchKernelGGL(block_bwd_mlp_kernel<PF32>, dim3(grid), dim3(256), smem, st, a);
     } else {
         const size_t smem = sizeof(MlpBwdSmem<PBF16>) + 256 * sizeof(float) + (PBF16::WAVES_BWD_MLP == 2 ? 24 : 36) * 1024;
-        int rc = set_smem(&block_bwd_mlp_kernel<PBF16>, smem, d1);
+        int rc = set_smem(&block_bwd_mlp_kernel<PBF16, false>, smem, d1);
+        if (!rc) rc = set_smem(&block_bwd_mlp_kernel<PBF16, true>, smem, d2);
         if (rc) return rc;
         ProfScope ps(K_BWD_MLP, st);
-        hipLaunchKernelGGL(block_bwd_mlp_kernel<PBF16>, dim3(grid), dim3(256), smem, st, a);
+        if (a.x1_bf16) hipLaunchKernelGGL((block_bwd_mlp_kernel<PBF16, true>), dim3(grid), dim3(256), smem, st, a);
+        else hipLaunchKernelGGL((block_bwd_mlp_kernel<PBF16, false>), dim3(grid), dim3(256), smem, st, a);
     }
     return (int)hipGetLastError();
 }

@@ -291,6 +291,30 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
         for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + (MSST_B4_COSEG ? 64 : 16) * j, 0, 0);
     };
+    // The same copy-out by ONE wave (wave O of head A, at the end of its phase 3: it has no phase 4 and sits out ~1.5 k cycles in
+    // front of barrier B3, while head B's phase 1 -- where the copy-out used to be -- is the longest stretch of ITS interval; cycle
+    // stamps, LABNOTES round 4): four passes of 16 rows, a lane <-> 16 bytes of a row's 64-byte piece, three pieces per row.
+#ifndef MSST_B4_COW
+#define MSST_B4_COW 2   // 0: head B, behind its phase 1 (round 3); 1: wave O of head A alone at the end of its phase 3 (1.3 k cycles for one wave: it becomes the last arriver); 2: all four waves of head A there, a quarter each (-0.5 %)
+#endif
+    auto copy_out_wave = [&]() {
+        const int l_ = launder3(tid) & 63;
+        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(a.ntok * 192), 0x00020000);
+        const unsigned rstride = (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = 16 * p + (l_ >> 2);
+            const unsigned sp = rowmap[row];
+            const int bs = seqout[min((int)(sp >> 16), 64)];
+            const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + (sp & 0xffffu) * rstride + (unsigned)(l_ & 3) * 16u;
+            u32x4 v[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                v[j] = *reinterpret_cast<const lds_u32x4*>(sm + R4_OUT + row * 192 + (((4 * j) | ((l_ & 3) ^ fz2(row))) << 4));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 64 * j, 0, 0);
+        }
+    };
     // phase-1 weight fragments [d tile][k step]: tile invariant, but 48 registers the softmax phase has no room for -- all twelve
     // are re-requested from L2 during phase 4 of the tile before (the rows no longer pass registers: a ring of eight refilled
     // inside phase 1 left its last two k-steps waiting on L2)
@@ -355,6 +379,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     c[1][0] = mma32(w1[1][ks], fb[ks % 3][0], c[1][0]);
                     c[1][1] = mma32(w1[1][ks], fb[ks % 3][1], c[1][1]);
                 });
+            R4_STAMP(12);
             {
                 const int l = t_ & 63, g = l >> 4, c16 = l & 15, fzc = fz(c16);
                 p2a[0] = gb + c16 * 128 + ((g ^ fzc) << 4);          // (gb: no bits below 16 K, commutes with the XORs)
@@ -374,7 +399,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (!(MSST_B3_EXP & 1024) && grp && ks != 0) copy_out();
+        if (!(MSST_B3_EXP & 1024) && !MSST_B4_COW && grp && ks != 0) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
@@ -590,6 +615,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 c[1][1] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][1], c[1][1]);
                 MSST_SCHED_FENCE();
             }
+            R4_STAMP(11);
             s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
@@ -636,6 +662,9 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             };
 #pragma unroll
             for (int k12 = 0; k12 < MSST_B3_W4; ++k12) w4[k12] = ld_w4(k12);
+            // copy-out of the tile of the walk step before (complete since barrier B2: head B's phase 4 ran two intervals behind)
+            if (MSST_B4_COW == 1 && !(MSST_B3_EXP & 1024) && wv == 3 && ks != 0) copy_out_wave();
+            if (MSST_B4_COW == 2 && !(MSST_B3_EXP & 1024) && !grp && ks != 0) copy_out();   // (2: all four waves of head A, a quarter each)
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
@@ -643,6 +672,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // the weight-gradient GEMM runs BEHIND barrier B3 (the rows it reads stay put: the next tile's go to the other row
             // buffer): phases 1 | 3 and 2 | 4 of the two heads, which share the barrier intervals, are then of equal length
             if (!(MSST_B3_EXP & 64)) wgrad();
+            R4_STAMP(9);
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
             if (roleO) {
                 if (QUEUE && !grp && (tid & 63) == 0) qt[(ks + 2) & 3] = qpend;   // published by barrier B4; first read at the top of walk step ks + 1 (wave O: next tile's bases)
@@ -664,6 +694,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         if (k12 + MSST_B3_W4 < 12) w4[k12 % MSST_B3_W4] = ld_w4(k12 + MSST_B3_W4);
                         if (k12 == MSST_B3_W1AT) load_w1();   // the next tile's phase-1 weights, behind this phase's last weight request
                     });
+                R4_STAMP(10);
                 // head A stages its rows; head B, two phases later, adds its own onto them (fp32 add of the bf16 values, one rounding)
                 const unsigned L9 = R4_OUT + l31 * 192 + (fz2(l31) << 4) + 8 * hi + 64 * wave;
 #pragma unroll
@@ -672,6 +703,17 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const unsigned o = (L9 ^ (q4 << 4)) + rt * 6144;
                         f32x4 t4 = {c4[rt][4 * q4], c4[rt][4 * q4 + 1], c4[rt][4 * q4 + 2], c4[rt][4 * q4 + 3]};
+#ifndef MSST_B4_PKADD
+#define MSST_B4_PKADD 0   // 1: head B adds its rows onto head A's with ds_pk_add_bf16 (LDS atomic, two bf16 per instruction) instead of read - add - write
+#endif
+                        if (MSST_B4_PKADD && grp) {
+                            const s16x4 b4 = f2bf4(t4);
+                            const unsigned w0 = (unsigned)(unsigned short)b4[0] | ((unsigned)(unsigned short)b4[1] << 16);
+                            const unsigned w1_ = (unsigned)(unsigned short)b4[2] | ((unsigned)(unsigned short)b4[3] << 16);
+                            const unsigned la = (unsigned)(uintptr_t)(sm + o);
+                            asm volatile("ds_pk_add_bf16 %0, %1\n\tds_pk_add_bf16 %0, %2 offset:4" :: "v"(la), "v"(w0), "v"(w1_) : "memory");
+                            continue;
+                        }
                         if (grp) {
                             const s16x4 o4 = *reinterpret_cast<const lds_s16x4*>(sm + o);
 #pragma unroll

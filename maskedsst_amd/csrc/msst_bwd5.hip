@@ -89,7 +89,7 @@ __device__ __forceinline__ float oct_sum5(float v) {
 // QUEUE (data parallel, opt-in): tiles drawn from one agent-scope counter instead of the static partition tile = workgroup +
 // k grid, so that a workgroup whose CU is held by a communication kernel draws fewer tiles instead of running its whole share
 // behind the others (see msst_bwd4.hip).  L wave 0 draws five walk steps ahead and publishes through an eight-entry LDS ring.
-template <int NP, bool DROP, bool QUEUE>
+template <int NP, bool DROP, bool QUEUE, bool X1B>
 __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     typedef LmSmem SM;
     constexpr int KS = 32, LDX = SM::LDX, LDH = SM::LDH;
@@ -370,9 +370,8 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         const int tile_ = valid_step(k) ? tile_at(k) : 0;
         const long t_ = (long)tile_ * 64 + wave * 16 + c;
         const long tokc = t_ < a.ntok ? t_ : 0;
-        const float* xs = a.x1 + tokc * 96 + 4 * g;
 #pragma unroll
-        for (int mt = 0; mt < 6; ++mt) xrow[mt] = *reinterpret_cast<const f32x4*>(xs + mt * 16);
+        for (int mt = 0; mt < 6; ++mt) xrow[mt] = ld_x1_4<X1B>(a.x1, tokc, mt * 16 + 4 * g);
     };
     request_rows(0);
     __syncthreads();
@@ -579,18 +578,18 @@ int launch_block_bwd_ln1mlp(const LnMlpArgs& a, int grid, hipStream_t st) {
     if (grid > ntiles) grid = ntiles;
 #define MSST_B5_FOR_ALL(X) X(1, false) X(1, true) X(2, false) X(2, true) X(3, false) X(3, true) X(4, false) X(4, true)
     if (!attr_set) {
-#define MSST_B5_ATTR(np, dr) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, false>), \
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; \
-                               e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, true>), \
+#define MSST_B5_ATTR1(np, dr, q, xb) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, q, xb>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; }
+#define MSST_B5_ATTR(np, dr) MSST_B5_ATTR1(np, dr, false, false) MSST_B5_ATTR1(np, dr, true, false) MSST_B5_ATTR1(np, dr, false, true) MSST_B5_ATTR1(np, dr, true, true)
         MSST_B5_FOR_ALL(MSST_B5_ATTR)
         attr_set = true;
     }
     ProfScope ps(K_BWD_LN1MLP, st);
     const bool dr = a.drop_i.thr != 0 || a.drop_p.thr != 0;
+#define MSST_B5_LAUNCH1(np, drv, q, xb) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, q, xb>), dim3(grid), dim3(512), smem, st, a)
 #define MSST_B5_LAUNCH(np, drv) if (a.nparts == np && dr == drv) { \
-        if (a.queue) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, true>), dim3(grid), dim3(512), smem, st, a); \
-        else hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, false>), dim3(grid), dim3(512), smem, st, a); }
+        if (a.queue) { if (a.x1_bf16) MSST_B5_LAUNCH1(np, drv, true, true); else MSST_B5_LAUNCH1(np, drv, true, false); } \
+        else { if (a.x1_bf16) MSST_B5_LAUNCH1(np, drv, false, true); else MSST_B5_LAUNCH1(np, drv, false, false); } }
     MSST_B5_FOR_ALL(MSST_B5_LAUNCH)
     return (int)hipGetLastError();
 }

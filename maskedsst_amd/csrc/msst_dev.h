@@ -317,6 +317,21 @@ struct Drop {
     float scale;
     int layer;            // block index (0 .. 2*depth-1)
 };
+// four consecutive features of a saved mid-residual row as fp32: the row is fp32 (16-byte load) or, X1B (MSST_X1_BF16), bf16
+// (8-byte load, widened by a shift: exact)
+template <bool X1B>
+__device__ __forceinline__ f32x4 ld_x1_4(const float* base, long tok, int m0) {
+    if constexpr (X1B) {
+        const s16x4 h = *reinterpret_cast<const s16x4*>(reinterpret_cast<const unsigned short*>(base) + tok * 96 + m0);
+        f32x4 r;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = __builtin_bit_cast(float, (unsigned)(unsigned short)h[i] << 16);
+        return r;
+    } else {
+        return *reinterpret_cast<const f32x4*>(base + tok * 96 + m0);
+    }
+}
+
 // 64 mask bits (four 16-bit fields) of element group `group`: three 32-bit multiplies (the quarter-rate
 // instruction here) instead of the six of a double murmur finaliser; keep rates / field and neighbour correlations
 // checked in numpy over 4M groups (|corr| < 2e-3).

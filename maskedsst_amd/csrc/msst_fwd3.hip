@@ -279,7 +279,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    if ((MSST_F3_EXP & 64) && t > 0) continue;   // (64: timing experiment, a quarter of the projection MFMAs)
+                                    if (((MSST_F3_EXP & 64) && t > 0) || (MSST_F3_EXP & 256)) continue;   // (64: timing experiment, a quarter of the projection MFMAs; 256: none)
                                     ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
                                     cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    if ((MSST_F3_EXP & 64) && t > 0) continue;
+                                    if (((MSST_F3_EXP & 64) && t > 0) || (MSST_F3_EXP & 256)) continue;
                                     cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
                                     ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
@@ -335,11 +335,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            if (!((NM[u] >> t) & 1u)) { s[u][t] = zero4(); continue; }
+                            if (!((NM[u] >> t) & 1u) || (MSST_F3_EXP & 512)) { s[u][t] = zero4(); continue; }   // (512: timing experiment, no attention arithmetic at all)
                             s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
                             if (!(MSST_F3_EXP & 128)) s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);   // (128: timing experiment, half the attention MFMAs)
                         }
-                    if (!(MSST_F3_EXP & 4)) {
+                    if (!(MSST_F3_EXP & (4 | 512))) {
                         // bit position of key 16 t + 4 g + r inside its 32-bit half of a 64-bit row mask: 16 (t & 1) + 4 g + r
                         int lq = threadIdx.x & 63;
                         asm volatile("" : "+v"(lq));
@@ -440,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                         for (int dd = 0; dd < 4; ++dd) {
                             o[u][dd] = zero4();
+                            if (MSST_F3_EXP & 512) { o[u][dd] = __builtin_bit_cast(f32x4, vA[dd][0]) ; continue; }
                             if (NM[u] & 3u) o[u][dd] = P::mma(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
                             if ((NM[u] & 12u) && !(MSST_F3_EXP & 128)) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
                         }
@@ -591,7 +592,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 o4 = o4 + xr[jj][i];
                 x1r[jj][i] = o4;
                 s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
-                if (a.x1 && tok >= 0) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+                if (a.x1 && tok >= 0) {   // saved for the MLP-half backward: fp32, or (MSST_X1_BF16) bf16 -- a quarter of this kernel's writes less
+                    if (a.x1_bf16) *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(o4);
+                    else *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+                }
             }
             const float mw = colgroup_sum(s1) * (1.f / 48.f);
             float m2 = 0.f;

@@ -32,6 +32,7 @@ struct BlockArgs {
     const float* x;   // [tokens][96] block input (residual stream, fp32)
     float* y;         // [tokens][96] block output
     float* x1;        // [tokens][96] mid-block residual (x + attn), saved for the backward; may be null
+    int x1_bf16;      // MSST_X1_BF16: x1 holds bf16 (role-split forward only)
     void* xn_out;     // optional [tokens][96] bf16: LN1(x) exactly as the block used it, saved for the attention backward (head-per-wave kernel only)
     TileMap tm;
     int ntiles, max_grid, H;
@@ -84,6 +85,7 @@ struct MlpBwdArgs {
     void* dab;   // optional [tokens][96] bf16: dx1 with the to_out dropout (site 2) applied, packed -- what the bf16 attention backward feeds its MFMAs
     long ntok;
     Drop drop;
+    int x1_bf16;  // MSST_X1_BF16: x1 holds bf16 (bf16 kernel only)
 };
 
 struct AttnBwdArgs {
@@ -115,7 +117,8 @@ struct LnMlpArgs {
     const float* x;          // [tokens][96] input of block i (= output of block i - 1)
     float* dx1;              // in: dx1 of block i (gradient at its mid residual); out: dx1 of block i - 1 (same rows, in place)
     const void* dxn_part;    // [nparts][tokens][96] bf16 partial d(LN1 out) of block i
-    const float* x1;         // [tokens][96] mid residual of block i - 1
+    const float* x1;         // [tokens][96] mid residual of block i - 1 (fp32, or bf16 with x1_bf16)
+    int x1_bf16;
     void* dab;               // out: [tokens][96] bf16, dx1 of block i - 1 with the to_out dropout applied (attention half's operand)
     float* slab_mlp;         // [grid][MSST_MLP_SLAB_N]
     float* slab_ln1;         // [grid][288]

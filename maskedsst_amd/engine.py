@@ -231,16 +231,20 @@ class Engine:
         acts = [x0]
         x1s = []
         x = x0
+        flags = _kernel_flags()
+        # bf16 x1 rows (MSST_X1_BF16): only the role-split forward writes them -- bf16, 8 heads, no kernel-selection flags;
+        # MSST_X1_BF16=0 keeps fp32 rows.  The x1 tensor's dtype tells the backward which kind it holds.
+        x1_bf16 = (save and self.prec == PREC_BF16 and H == 8 and flags == 0 and os.environ.get("MSST_X1_BF16", "1") != "0")
         for i, (sname, l) in enumerate(self._layers()):
             y = torch.empty_like(x)
-            x1 = torch.empty_like(x) if save else None
+            x1 = (torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if x1_bf16 else torch.empty_like(x)) if save else None
             # bf16: the block also saves LN1(x) as it used it (bf16 rows), if the selected kernel can; the attention backward
             # then skips its own LN1.  The buffer rides on the x1 tensor object so that every caller keeps its (acts, x1s) pair.
             xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (save and self.prec != PREC_F32) else None
             wrote = ctypes.c_int(0)
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
             _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec | _kernel_flags(), self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
+                                               self.prec | flags | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
                                                _stream()),
                        "msst_block_fwd")
             if x1 is not None:
@@ -331,6 +335,10 @@ class Engine:
         layers = self._layers()
         flags = _kernel_flags()
         xns = [getattr(t, "_msst_xn", None) for t in x1s]
+        x1_bf16 = len(x1s) > 0 and all(t.dtype == torch.bfloat16 for t in x1s)
+        if not x1_bf16 and any(t.dtype != torch.float32 for t in x1s):
+            raise ValueError("saved x1 rows of mixed dtypes")
+        x1flag = _lib.X1_BF16 if x1_bf16 else 0
         # Chained backward (msst_block_bwd_chain): the LN1 backward of block i and the MLP-half backward of block i - 1 are
         # one launch, dx of block i stays on chip.  bf16 tuned kernels with saved LN1 rows only; at most four d(LN1 out)
         # partials (one per head pair for an even head count, else one per head).
@@ -371,7 +379,7 @@ class Engine:
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
                     _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab_i), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(dab),
+                    B, S, N, H, self.prec | x1flag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(dab),
                     1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
                 if not defer:
@@ -395,7 +403,7 @@ class Engine:
             _lib.check(self.lib.msst_block_bwd(
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
-                self.prec | flags,
+                self.prec | flags | x1flag,
                 drop[0], drop[1], i, _p(xns[i]), _p(dab), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")

@@ -339,3 +339,46 @@ def test_deferred_slab_reduction_is_bit_identical(cfg, drop, monkeypatch):
     assert float(g_d.abs().max()) > 0.0
     bad = [name for name, p in eng.trainable() if not torch.equal(eng.fp.view(name, g_d), eng.fp.view(name, g_i))]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg", [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4)], ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_bf16_x1_rows(cfg, monkeypatch):
+    """MSST_X1_BF16 (round 4): the forward saves the mid-block residual x1 as bf16 rows instead of fp32, the MLP-half backward
+    (standalone and fused with LN1) widens them.  The saved rows are exactly the rounded fp32 ones; the gradients move by what
+    the LN2 statistics of rounded rows move them -- a bf16-level difference, held against the fp32-row backward here and, like
+    every bf16 path, against the oracle in test_gpu_dropout / test_gpu_depth12 (which run with bf16 rows by default)."""
+    drop = (0.1, 777)
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+
+    def run(flag):
+        monkeypatch.setenv("MSST_X1_BF16", flag)
+        out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+        torch.manual_seed(11)
+        dy = torch.randn_like(out["enc_out"]) * 1e-3
+        eng.fp.grad.zero_()
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy, drop=drop)
+        torch.cuda.synchronize()
+        return out, dx0.clone(), eng.fp.grad.clone()
+
+    o16, dx16, g16 = run("1")
+    o32, dx32, g32 = run("0")
+    monkeypatch.delenv("MSST_X1_BF16")
+    assert all(t.dtype == torch.bfloat16 for t in o16["x1s"]) and all(t.dtype == torch.float32 for t in o32["x1s"])
+    assert torch.equal(o16["enc_out"], o32["enc_out"])                      # the forward itself does not change
+    for a, b in zip(o16["x1s"], o32["x1s"]):
+        assert torch.equal(a, b.to(torch.bfloat16))                         # round-to-nearest-even of the same fp32 rows
+    e_dx = rel_l2(dx16, dx32)
+    worst, bad = 0.0, []
+    for name, p in eng.trainable():
+        b = eng.fp.view(name, g32)
+        if float(b.abs().max()) == 0.0:
+            continue
+        e = rel_l2(eng.fp.view(name, g16), b)
+        worst = max(worst, e)
+        if not e < 6e-3:
+            bad.append((name, e))
+    record("bf16_x1_rows", cfg=cfg, dx=e_dx, worst_grad=worst)
+    assert e_dx < 2e-3, e_dx
+    assert not bad, bad

@@ -41,7 +41,9 @@ for i in (0, 1):
     s = buf.cpu().numpy()
     t0 = min(int(s[16 * w]) for w in range(8))
     for w in range(8):
-        st = [int(s[16 * w + k]) for k in range(10)]
-        d = [st[k + 1] - st[k] for k in range(9)]
-        print(f"{sname} head {'AB'[w >> 2]} wave {'QKVO'[w & 3]}: start {st[0] - t0:6d} total {st[9] - st[0]:6d} | " + " ".join(f"{n}:{v}" for n, v in zip(names, d)))
+        st = [int(s[16 * w + k]) for k in range(13)]
+        d = [st[k + 1] - st[k] for k in range(8)]
+        # sub-phase stamps: 12 = phase 1's MFMAs done, 11 = phase 3's contraction done, 9 = weight-gradient GEMM done, 10 = phase 4's MFMAs done
+        sub = f"p1 mfma {st[12] - st[0]} | p3 mfma {st[11] - st[4]} | wgrad {st[9] - st[6]} p4 mfma {(st[10] - st[9]) if st[10] else 0} p4 epi {(st[7] - st[10]) if st[10] else st[7] - st[9]}"
+        print(f"{sname} head {'AB'[w >> 2]} wave {'QKVO'[w & 3]}: start {st[0] - t0:6d} total {st[8] - st[0]:6d} | " + " ".join(f"{n}:{v}" for n, v in zip(names, d)) + " || " + sub)
 os.environ["MSST_DBG"] = "0"
