@@ -377,8 +377,11 @@ def test_bf16_x1_rows(cfg, monkeypatch):
             continue
         e = rel_l2(eng.fp.view(name, g16), b)
         worst = max(worst, e)
-        if not e < 6e-3:
+        if not e < 1.8e-2:
             bad.append((name, e))
     record("bf16_x1_rows", cfg=cfg, dx=e_dx, worst_grad=worst)
-    assert e_dx < 2e-3, e_dx
+    # measured (profiles/r04_parity_measured.jsonl): dx 0.95e-3 / 1.1e-3, worst gradient tensor 4.9e-3 / 5.2e-3 -- the size of every
+    # other bf16 rounding-point difference; against the oracle the as-benchmarked gradients do not move (worst 5.18e-3 -> 5.20e-3,
+    # median 2.66e-3 -> 2.67e-3).  Bars at 3.5x measured.
+    assert e_dx < 4e-3, e_dx
     assert not bad, bad
