@@ -15,8 +15,10 @@
 //     exchange), the same rows x hidden half mh of the first MLP GEMM and x output half mh of the second.
 // Four barriers per tile (the middle and the end of each round) are the only synchronisation: every cross-wave hand-over of
 // the R pipeline (LN2 statistics of the two feature halves, LN2 rows, GELU rows) is placed across one of them.
-// Measured: 293 -> 258 us per launch (B = 256, EnMAP shape).  What bounds it now is instruction issue per SIMD (MFMA passes +
-// 4-cycle VALU issues: 91 % of the wall cycles by the counters), not latency: see DESIGN.md section 5 / LABNOTES.md round 4.
+// Measured: 293 -> 256 us per launch (B = 256, EnMAP shape; 252-262 us for the spatial launches, 266-274 for the spectral ones).
+// What bounds it: the A wave is ONE in-order instruction stream per SIMD (11.7 k cycles per head alone: projections 3.1 k, their
+// weight stream 1.4 k, attention MFMAs 1.3 k, softmax arithmetic 1.2 k, packing / stores / barriers the rest) and every piece costs about
+// its own issue time (timing-only builds: MSST_F3_EXP); the R waves' path is 178 us on its own.  DESIGN.md section 5, LABNOTES.md round 4.
 //
 //   interval   A waves (tile k)                 R waves
 //   q0         round 0: projections, j = 0, 1   out-projection K half 1 of tile k-1 (O of round 1), bias / dropout / +x -> x1,
@@ -59,7 +61,9 @@
 #endif
 #ifndef MSST_F3_EXP
 #define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic,
-                        // 8 = every q / k / v weight request reads the same two fragments, 16 = no q / k / v weight requests inside the walk at all
+                        // 8 = every q / k / v weight request reads the same two fragments, 16 = no q / k / v weight requests inside the walk at all,
+                        // 32 = (MSST_F3_KM) the R waves do not hash, 64 = a quarter of the projection MFMAs, 128 = half the attention MFMAs (and the
+                        // projections they no longer need), 256 = no projection MFMAs, 512 = no attention arithmetic at all
 #endif
 
 #ifdef MSST_STAMPS
