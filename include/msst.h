@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSST_VERSION 102
+#define MSST_VERSION 103
 #define MSST_DIM 96
 #define MSST_DIM_HEAD 64
 #define MSST_MLP 64
@@ -38,7 +38,6 @@ extern "C" {
  * the library never reads the environment and keeps no per-call state. */
 #define MSST_KERNEL_GENERIC (16 << 8)    /* generic template kernels also in bf16 (fwd and attention bwd)   */
 #define MSST_KERNEL_FWD_4WAVE (64 << 8)  /* bf16 forward: tuned 4-wave kernel instead of head-per-wave      */
-#define MSST_KERNEL_FWD_HW (256 << 8)    /* bf16 forward, 8 heads: the lockstep head-per-wave kernel (msst_fwd2.hip) instead of the role-split one (msst_fwd3.hip) */
 #define MSST_X1_BF16 (1024 << 8)         /* the saved mid-residual rows x1 are bf16 instead of fp32: msst_block_fwd writes them so (role-split bf16 forward only:
                                             8 heads, no MSST_KERNEL_* flag; MSST_ERR_UNSUPPORTED otherwise), msst_block_bwd / _chain read x1 and x1_prev so (bf16
                                             kernels only).  A quarter of the forward's writes and 8 % of the fused row-local backward's reads less; the LN2 statistics
@@ -67,8 +66,12 @@ typedef struct MsstPrepJob {
 } MsstPrepJob;
 
 /* Converts / transposes all matrices of the model into operand layout in ONE launch.
- * `jobs` is a DEVICE array. max_elems = max(rows*cols) over jobs. */
-int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int max_elems, int prec, void* stream);
+ * `jobs` is a DEVICE array. max_elems = max(rows*cols) over jobs.  job_bytes = sizeof(MsstPrepJob) of the CALLER's header: a
+ * table laid out by another revision is refused (MSST_ERR_BADARG) instead of being read mis-strided.  err_flag (optional, one
+ * zeroed int32 in device memory): the kernel ORs in 1 for a job with a bad pack / shape and 2 for a pack = 1 job that is not
+ * whole fragments -- such jobs are skipped, their destinations stay unwritten; the host cannot see the table, so a caller
+ * that builds it should read the word back once after its first call. */
+int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int job_bytes, int max_elems, int prec, int32_t* err_flag, void* stream);
 
 /* Operand-layout weights of one transformer block (device pointers).
  * Replaces the parameters of reference vit_spatial_spectral.py:85-97 (one Transformer layer). */
@@ -111,12 +114,20 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
  * dropout_p > 0 enables the reference's four dropout sites (:38,40,57,62) with a stateless counter-based
  * mask keyed by (seed, layer, site, element); msst_block_bwd regenerates it from the same three values.
  * xn_out (optional, [tokens][96] bf16): receives LN1(x) exactly as the block used it, so that msst_block_bwd neither
- * re-reads x nor renormalises it; *xn_written (host, optional) tells whether the selected kernel wrote it (the two tuned
- * bf16 kernels do -- head-per-wave for 8 heads, 4-wave otherwise; the fp32 and MSST_KERNEL_GENERIC kernels do not) -- pass
- * xn_saved to msst_block_bwd only then. */
+ * re-reads x nor renormalises it.
+ * lse_out (optional, msst_block_lse_floats(...) fp32): receives, per (64-row tile, head, row), lse = log2 of the row's softmax
+ * denominator in the exponent domain of the kernels (p = exp2(s * dim_head^-0.5 * log2 e - lse), vit_spatial_spectral.py:71-73):
+ * the attention backward then computes the probabilities directly -- no row maximum, no row sum, no reciprocal.  10-11 MB per
+ * block at the bench shape; the tile order is the forward's own (same mode / shapes on both sides).
+ * *saved (host, optional) tells which of the two the selected kernel wrote: MSST_SAVED_XN (the two tuned bf16 kernels -- role
+ * split for 8 heads, 4-wave otherwise; not fp32, not MSST_KERNEL_GENERIC), MSST_SAVED_LSE (the role-split kernel only).  Pass
+ * xn_saved / lse_saved to msst_block_bwd only when the bit is set. */
+#define MSST_SAVED_XN 1
+#define MSST_SAVED_LSE 2
+long msst_block_lse_floats(int mode, int B, int S, int N, int heads);
 int msst_block_fwd(const MsstBlockWeights* w /*host*/, const float* x, float* y, float* x1, int mode,
                    int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed,
-                   int layer, void* xn_out, int* xn_written /*host*/, void* stream);
+                   int layer, void* xn_out, float* lse_out, int* saved /*host*/, void* stream);
 
 /* a12-a14: gather of masked tokens, BlockwiseToPixels (vit_simmim_original.py:9-40,314-330),
  * target gather from the raw cube (:335) and mean-L1 / K (:338).
@@ -162,6 +173,7 @@ int msst_block_bwd(const MsstBlockWeights* w /*host*/, const MsstBlockGrads* g /
                    const float* x1, const float* dy, float* dx, float* dx1, void* dxn_part, float* slab,
                    int grid_rows, int nchunk, int mode, int B, int S, int N, int heads, int prec,
                    float dropout_p, uint32_t seed, int layer, const void* xn_saved /*optional, see msst_block_fwd*/,
+                   const float* lse_saved /*optional, see msst_block_fwd; used together with xn_saved by the two-head attention backward*/,
                    void* dab_ws /*optional workspace [tokens][96] bf16, used together with xn_saved: the MLP half leaves the
                                   dropped bf16 copy of dx1 there for the attention half*/,
                    void* stream);
@@ -188,8 +200,8 @@ int msst_block_bwd_chain(const MsstBlockWeights* w /*host*/, const MsstBlockGrad
                          const MsstBlockWeights* w_prev /*host, block i - 1 or NULL*/, const MsstBlockGrads* g_prev /*host*/,
                          const float* x, const float* x1, const float* x1_prev, const float* dy, float* dx, float* dx1,
                          void* dxn_part, float* slab, int grid_rows, int nchunk, int mode, int B, int S, int N, int heads,
-                         int prec, float dropout_p, uint32_t seed, int layer, const void* xn_saved, void* dab_ws,
-                         int first, int32_t* tile_queue /*optional, MSST_TILE_QUEUE_WORDS int32 of device scratch*/, void* stream);
+                         int prec, float dropout_p, uint32_t seed, int layer, const void* xn_saved, const float* lse_saved /*optional*/,
+                         void* dab_ws, int first, int32_t* tile_queue /*optional, MSST_TILE_QUEUE_WORDS int32 of device scratch*/, void* stream);
 
 /* Deferred slab reduction for a RUN of msst_block_bwd_chain calls made with MSST_BWD_DEFER_REDUCE in `prec`: one launch instead of
  * one per block (the reduction is the only part of a block backward whose cost does not shrink with the problem: 62 MB of
@@ -222,6 +234,18 @@ int msst_cls_head_fwd(const float* y, const float* ln_g, const float* ln_b, cons
 int msst_cls_head_bwd(const float* y, const float* dlogits, const float* ln_g, const float* ln_b, const float* w,
                       float* dy, float* slab, float* dln_g, float* dln_b, float* dw, float* db, int B, int S,
                       int N, int n_classes, void* stream);
+
+/* a7: LayerNorm over the last axis as an op of its own (nn.LayerNorm of PreNorm, vit_spatial_spectral.py:25, and of the
+ * tokenizer, :194-195: eps 1e-5, affine, biased variance), fp32, rows of D <= 128 contiguous floats (D = 96 vectorised; D = 10 =
+ * the tokenizer's pixel rows).  On the hot path the same arithmetic runs fused into msst_tokenize_* / msst_block_*; these
+ * entry points serve a caller that needs a lone LayerNorm.  Row statistics are wave-shuffle (DPP) reductions.
+ * _fwd: mean / rstd [rows] are optional outputs.  _bwd: recomputes the statistics from x; dgamma / dbeta [D] are fully
+ * written (fixed summation order: bit-reproducible); slab: msst_layernorm_bwd_slab(rows, D) floats of scratch. */
+int msst_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean /*optional*/,
+                       float* rstd /*optional*/, long rows, int D, float eps, void* stream);
+long msst_layernorm_bwd_slab(long rows, int D);
+int msst_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                       float* slab, long rows, int D, float eps, void* stream);
 
 /* Fused AdamW over a flat fp32 buffer (torch.optim.AdamW semantics, src/utils.py:36-45), with the
  * reference's value clamp of the gradient (pretrain.py:71-73) when clamp > 0. */

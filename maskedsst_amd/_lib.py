@@ -9,6 +9,7 @@ from ctypes import c_int, c_int32, c_uint32, c_long, c_float, c_void_p, c_char_p
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libmsst.so")
+HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "msst.h"))
 
 PREC_F32 = 0
 PREC_BF16 = 1
@@ -42,24 +43,26 @@ class MsstBlockGrads(Structure):
 _P = c_void_p
 BWD_DEFER_REDUCE = 512 << 8   # include/msst.h: MSST_BWD_DEFER_REDUCE
 X1_BF16 = 1024 << 8           # include/msst.h: MSST_X1_BF16
+SAVED_XN, SAVED_LSE = 1, 2    # include/msst.h: MSST_SAVED_*
 _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),
-    "msst_prep_weights": (c_int, [_P, c_int, c_int, c_int, _P]),
+    "msst_prep_weights": (c_int, [_P, c_int, c_int, c_int, c_int, _P, _P]),
     "msst_tokenize_fwd": (c_int, [_P] * 9 + [c_int, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_uint32, _P]),
     "msst_cls_head_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_int, _P]),
     "msst_cls_head_bwd": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_int, _P]),
+    "msst_block_lse_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
-                               c_int, c_int, c_float, c_uint32, c_int, _P, POINTER(c_int), _P]),
+                               c_int, c_int, c_float, c_uint32, c_int, _P, _P, POINTER(c_int), _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                               c_int, _P]),
     "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,
                               c_int, c_int, _P]),
     "msst_block_bwd": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P,
-                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P, _P]),
+                               c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P, _P, _P]),
     "msst_block_bwd_chain": (c_int, [POINTER(MsstBlockWeights), POINTER(MsstBlockGrads), POINTER(MsstBlockWeights),
                                      POINTER(MsstBlockGrads), _P, _P, _P, _P, _P, _P, _P, _P,
-                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int, _P, _P, _P,
                                      c_int, _P, _P]),
     "msst_block_bwd_reduce": (c_int, [POINTER(MsstBlockGrads), POINTER(MsstBlockGrads), _P, ctypes.c_long, ctypes.c_long,
                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
@@ -73,6 +76,9 @@ _SIGS = {
     "msst_profile_kernels": (c_int, []),
     "msst_profile_name": (c_char_p, [c_int]),
     "msst_profile_collect": (c_int, [_P, _P]),
+    "msst_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_long, c_int, c_float, _P]),
+    "msst_layernorm_bwd_slab": (c_long, [c_long, c_int]),
+    "msst_layernorm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_long, c_int, c_float, _P]),
     "msst_adamw": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, c_float, c_int,
                            c_float, c_float, _P]),
 }
@@ -82,6 +88,16 @@ _lib = None
 
 def declared_symbols():
     return sorted(_SIGS)
+
+
+def header_version(path=None):
+    """MSST_VERSION of include/msst.h -- the revision this binding (and every struct layout in it) was written against"""
+    import re
+    with open(path or HEADER_PATH) as f:
+        m = re.search(r"^#define\s+MSST_VERSION\s+(\d+)", f.read(), re.M)
+    if not m:
+        raise MsstError(f"no MSST_VERSION in {path or HEADER_PATH}")
+    return int(m.group(1))
 
 
 def load():
@@ -100,6 +116,15 @@ def load():
             raise MsstError(f"libmsst.so does not export {name} (stale build? run python -m maskedsst_amd.build)")
         fn.restype = res
         fn.argtypes = args
+    # a library built from another revision of the header (a stale .so after a checkout: the build is mtime based and the
+    # prebuilt library travels with the tree) or a kernel-study build (-DMSST_LAB: msst_version() < 0, results wrong by
+    # design) is refused, not loaded
+    got, want = int(lib.msst_version()), header_version()
+    if got != want:
+        raise MsstError(
+            f"{LIB_PATH} reports msst_version() = {got}, include/msst.h says MSST_VERSION {want}: "
+            + ("a kernel-study build (-DMSST_LAB) must not be loaded by the product; " if got < 0 else "stale library; ")
+            + "rebuild with python -m maskedsst_amd.build --force")
     _lib = lib
     return lib
 

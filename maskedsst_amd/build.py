@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmsst.so")
-SOURCES = ["msst_fwd.hip", "msst_fwd2.hip", "msst_fwd3.hip", "msst_bwd.hip", "msst_bwd3.hip", "msst_bwd4.hip", "msst_bwd5.hip", "msst_opt.hip", "msst_api.hip"]
+SOURCES = ["msst_fwd.hip", "msst_fwd3.hip", "msst_bwd.hip", "msst_bwd3.hip", "msst_bwd4.hip", "msst_bwd5.hip", "msst_ln.hip", "msst_opt.hip", "msst_api.hip"]
 HEADERS = ["msst_dev.h", "msst_kernels.h", os.path.join("..", "..", "include", "msst.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
 

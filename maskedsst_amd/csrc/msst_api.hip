@@ -22,11 +22,18 @@ static int fail(int code, const char* what) {
 // weight prep: fp32 master -> operand element type, optional transpose.  One launch for all jobs.
 // ------------------------------------------------------------------------------------------
 template <class E>
-__global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jobs) {
+__global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jobs, int* err_flag) {
     const MsstPrepJob j = jobs[blockIdx.y];
-    // malformed jobs are skipped (the job table lives in device memory: the host entry point cannot validate it)
-    if (j.pack < 0 || j.pack > 1 || j.rows < 1 || j.cols < 1) return;
-    if (sizeof(E) == 2 && j.pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) return;
+    // malformed jobs are skipped (the job table lives in device memory: the host entry point cannot validate it) and reported
+    // through the caller's error word: bit 0 = bad pack / shape, bit 1 = pack 1 on a shape that is not whole 32 x 16 fragments
+    if (j.pack < 0 || j.pack > 1 || j.rows < 1 || j.cols < 1) {
+        if (err_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err_flag, 1);
+        return;
+    }
+    if (sizeof(E) == 2 && j.pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) {
+        if (err_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err_flag, 2);
+        return;
+    }
     const int n = j.rows * j.cols;
     E* dst = reinterpret_cast<E*>(j.dst);
     if constexpr (sizeof(E) == 2) {
@@ -180,7 +187,13 @@ using namespace msst;
 
 extern "C" {
 
+// a kernel-study build (-DMSST_LAB: timing modes that compute wrong results can be compiled in) identifies itself with a
+// negative version; maskedsst_amd/_lib.py refuses to load it
+#ifdef MSST_LAB
+int msst_version(void) { return -MSST_VERSION; }
+#else
 int msst_version(void) { return MSST_VERSION; }
+#endif
 const char* msst_last_error(void) { return g_err; }
 
 int msst_debug_stamps(void* buf) {
@@ -218,7 +231,7 @@ int msst_profile_kernels(void) { return K_COUNT; }
 const char* msst_profile_name(int id) {
     static const char* names[K_COUNT] = {"prep_weights", "tokenize_fwd", "block_fwd", "head_fwd", "loss_reduce",
                                          "head_bwd", "reduce_slabs", "block_bwd_mlp", "block_bwd_attn",
-                                         "attn_slab_reduce", "block_bwd_ln1", "tokenize_bwd", "pos_split", "adamw", "block_bwd_ln1mlp"};
+                                         "attn_slab_reduce", "block_bwd_ln1", "tokenize_bwd", "pos_split", "adamw", "block_bwd_ln1mlp", "layernorm"};
     return (id >= 0 && id < K_COUNT) ? names[id] : "?";
 }
 
@@ -237,15 +250,18 @@ int msst_profile_collect(double* total_ms, long* count) {
     return 0;
 }
 
-int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int max_elems, int prec, void* stream) {
+int msst_prep_weights(const MsstPrepJob* jobs, int njobs, int job_bytes, int max_elems, int prec, int32_t* err_flag, void* stream) {
+    // a caller built against another revision of MsstPrepJob would hand over a mis-strided table: refused on the host
+    if (job_bytes != (int)sizeof(MsstPrepJob)) return fail(MSST_ERR_BADARG, "msst_prep_weights (MsstPrepJob of another header revision)");
     if (njobs <= 0) return 0;
+    if (!jobs) return fail(MSST_ERR_BADARG, "msst_prep_weights");
     ProfScope ps(K_PREP, (hipStream_t)stream);
     int gx = (max_elems + 256 * 4 - 1) / (256 * 4);
     if (gx < 1) gx = 1;
     if (gx > 64) gx = 64;
     dim3 grid(gx, njobs);
-    if (prec == MSST_PREC_F32) hipLaunchKernelGGL(prep_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
-    else hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs);
+    if (prec == MSST_PREC_F32) hipLaunchKernelGGL(prep_weights_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, jobs, (int*)err_flag);
+    else hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, jobs, (int*)err_flag);
     return fail((int)hipGetLastError(), "msst_prep_weights");
 }
 
@@ -261,9 +277,14 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
     return fail(launch_tokenize_fwd(a, (hipStream_t)stream), "msst_tokenize_fwd");
 }
 
+long msst_block_lse_floats(int mode, int B, int S, int N, int heads) {
+    if (B < 1 || S < 1 || N < 1 || heads < 1 || N > 64 || S > 64) return 0;
+    return (long)ntiles_of(make_tilemap(mode, B, S, N)) * heads * 64;
+}
+
 int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x1, int mode, int B, int S,
                    int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed, int layer,
-                   void* xn_out, int* xn_written, void* stream) {
+                   void* xn_out, float* lse_out, int* saved, void* stream) {
     if (!bw_ok(w) || !x || !y || x == y) return fail(MSST_ERR_BADARG, "msst_block_fwd (null argument, or MsstBlockWeights of another header revision)");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (sequence length > 64)");
     const int dbg = (prec >> 8) & 0xffff;   // MSST_KERNEL_* selection flags ride in the upper bits of `prec`
@@ -284,11 +305,12 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
 #endif
     // MSST_X1_BF16: only the role-split forward (bf16, 8 heads, no kernel selection flags) writes bf16 x1 rows
     a.x1_bf16 = (dbg & 1024) ? 1 : 0;
-    if (a.x1_bf16 && !(prec == MSST_PREC_BF16 && heads == 8 && !(dbg & (16 | 64 | 256))))
+    if (a.x1_bf16 && !(prec == MSST_PREC_BF16 && heads == 8 && !(dbg & (16 | 64))))
         return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (MSST_X1_BF16 needs the role-split bf16 forward: 8 heads, no MSST_KERNEL_* flags)");
     a.drop = make_drop(dropout_p, seed, layer);
     a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
-    if (xn_written) *xn_written = a.xn_out ? 1 : 0;
+    a.lse_out = (lse_out && block_fwd_writes_lse(a, prec)) ? lse_out : nullptr;
+    if (saved) *saved = (a.xn_out ? MSST_SAVED_XN : 0) | (a.lse_out ? MSST_SAVED_LSE : 0);
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 
@@ -400,8 +422,8 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
                           const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
                           const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                           int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                          uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int chain, int first, int32_t* tile_queue,
-                          hipStream_t st) {
+                          uint32_t seed, int layer, const void* xn_saved, const float* lse_saved, void* dab_ws, int chain, int first,
+                          int32_t* tile_queue, hipStream_t st) {
     if (!bw_ok(w) || (w_prev && !bw_ok(w_prev)) || !g || grid_rows < 1 || nchunk < 1)
         return fail(MSST_ERR_BADARG, "msst_block_bwd (null argument, or MsstBlockWeights of another header revision)");
     if (N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_bwd (sequence length > 64)");
@@ -449,6 +471,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         aa.xn = fast_rows ? xn_saved : nullptr; aa.dab = fast_rows ? dab_ws : nullptr;
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
         aa.queue = (tile_queue && heads / 2 <= 32) ? tile_queue : nullptr;
+        aa.lse = fast_rows ? lse_saved : nullptr;   // (only the two-head kernel reads it; launch_block_bwd_attn drops it for the others)
         aa.dbg = dbg & ~8;
         aa.stamps = nullptr;
 #ifdef MSST_STAMPS
@@ -492,18 +515,19 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
 int msst_block_bwd(const MsstBlockWeights* w, const MsstBlockGrads* g, const float* x, const float* x1,
                    const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                    int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                   uint32_t seed, int layer, const void* xn_saved, void* dab_ws, void* stream) {
+                   uint32_t seed, int layer, const void* xn_saved, const float* lse_saved, void* dab_ws, void* stream) {
     return block_bwd_impl(w, g, nullptr, nullptr, x, x1, nullptr, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
-                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 0, 0, nullptr, (hipStream_t)stream);
+                          heads, prec, dropout_p, seed, layer, xn_saved, lse_saved, dab_ws, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 int msst_block_bwd_chain(const MsstBlockWeights* w, const MsstBlockGrads* g, const MsstBlockWeights* w_prev,
                          const MsstBlockGrads* g_prev, const float* x, const float* x1, const float* x1_prev,
                          const float* dy, float* dx, float* dx1, void* dxn_part, float* slab, int grid_rows,
                          int nchunk, int mode, int B, int S, int N, int heads, int prec, float dropout_p,
-                         uint32_t seed, int layer, const void* xn_saved, void* dab_ws, int first, int32_t* tile_queue, void* stream) {
+                         uint32_t seed, int layer, const void* xn_saved, const float* lse_saved, void* dab_ws, int first,
+                         int32_t* tile_queue, void* stream) {
     return block_bwd_impl(w, g, w_prev, g_prev, x, x1, x1_prev, dy, dx, dx1, dxn_part, slab, grid_rows, nchunk, mode, B, S, N,
-                          heads, prec, dropout_p, seed, layer, xn_saved, dab_ws, 1, first, tile_queue, (hipStream_t)stream);
+                          heads, prec, dropout_p, seed, layer, xn_saved, lse_saved, dab_ws, 1, first, tile_queue, (hipStream_t)stream);
 }
 
 int msst_block_bwd_reduce(const MsstBlockGrads* g, const MsstBlockGrads* g_prev, float* slab, long slab_stride, long grad_stride,
@@ -589,6 +613,28 @@ int msst_cls_head_bwd(const float* y, const float* dlogits, const float* ln_g, c
     ok = ok && rb.add(slab + n_classes * 96 + n_classes + 96, ss, B, dln_b, 96);
     if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_cls_head_bwd");
     return fail(launch_reduce_segs(rb.r, st), "msst_cls_head_bwd(reduce)");
+}
+
+int msst_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd, long rows,
+                       int D, float eps, void* stream) {
+    return fail(launch_layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps, (hipStream_t)stream), "msst_layernorm_fwd");
+}
+
+long msst_layernorm_bwd_slab(long rows, int D) { return rows < 1 || D < 1 ? 0 : (long)layernorm_bwd_grid(rows, D) * 2 * D; }
+
+int msst_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* slab,
+                       long rows, int D, float eps, void* stream) {
+    if (!dgamma || !dbeta) return fail(MSST_ERR_BADARG, "msst_layernorm_bwd");
+    if (rows == 0) return 0;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = layernorm_bwd_grid(rows, D);
+    int rc = launch_layernorm_bwd(x, gamma, dy, dx, slab, grid, rows, D, eps, st);
+    if (rc) return fail(rc, "msst_layernorm_bwd");
+    RSegBuilder rb;
+    bool ok = rb.add(slab, 2L * D, grid, dgamma, D);
+    ok = ok && rb.add(slab + D, 2L * D, grid, dbeta, D);
+    if (!ok) return fail(MSST_ERR_UNSUPPORTED, "msst_layernorm_bwd");
+    return fail(launch_reduce_segs(rb.r, st), "msst_layernorm_bwd(reduce)");
 }
 
 int msst_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,

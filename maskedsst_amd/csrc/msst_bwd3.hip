@@ -40,9 +40,6 @@
 #ifndef MSST_B3_W1AT
 #define MSST_B3_W1AT 6   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
 #endif
-#ifndef MSST_B3_EXP
-#define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = no row requests
-#endif
 #ifndef MSST_B3_PRIO
 #define MSST_B3_PRIO 1   // s_setprio level of the MFMA-dense phases (1, 3, 4); the softmax phase and the copy-out run at 0
 #endif
@@ -112,7 +109,7 @@ __device__ __forceinline__ s16x8 ld_w32(const void* w, int f, int lane16) {
     return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, f * 1024, 0));
 }
 __device__ __forceinline__ void bar3() {
-    if (MSST_B3_EXP & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else lds_barrier();
+    lds_barrier();
 }
 __device__ __forceinline__ int launder3(int v) {
     asm volatile("" : "+v"(v));
@@ -190,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
     // and stored into XN / DA -- dead from barrier B3 on -- before barrier B4.  Padding rows: clamped address, zeros stored.
     auto load_rows = [&](int tile_, u32x4 (&xr)[3], u32x4 (&dr)[3]) -> int {
         const int t_ = launder3(tid);
-        const int tok = (MSST_B3_EXP & 4) ? 0 : tok_sp(tile_, rowmap[t_ >> 2]);
+        const int tok = tok_sp(tile_, rowmap[t_ >> 2]);
         const long off = (long)(tok >= 0 ? tok : 0) * 96 + (t_ & 3) * 24;
         const u32x4* sx = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(a.xn) + off);
         const u32x4* sd = reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(a.dab) + off);
@@ -218,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) W1_(dt, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 * dt + ks, l16);
+            for (int ks = 0; ks < 4; ++ks) W1_(dt, ks) = ld_w32(w1p, f1_0 + 6 * dt + ks, l16);
     };
     load_w1();
     lds_barrier();   // the first tile's rows are in XN / DA
@@ -264,8 +261,8 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     c[1][0] = mma32(W1_(1, ks & 3), fb[ks % 3][0], c[1][0]);
                     c[1][1] = mma32(W1_(1, ks & 3), fb[ks % 3][1], c[1][1]);
                     if (ks < 2) {
-                        W1_(0, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + ks + 4, (t_ & 63) * 16);
-                        W1_(1, ks) = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + 6 + ks + 4, (t_ & 63) * 16);
+                        W1_(0, ks) = ld_w32(w1p, f1_0 + ks + 4, (t_ & 63) * 16);
+                        W1_(1, ks) = ld_w32(w1p, f1_0 + 6 + ks + 4, (t_ & 63) * 16);
                     }
                 });
             const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
@@ -404,7 +401,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                     lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
             };
-            if (!(MSST_B3_EXP & 16)) {
+            {
                 if (L == 64) softmax_phase(std::integral_constant<int, -1>{});
                 else switch (need) {   // (wave uniform, tile invariant)
                     case 0x3: softmax_phase(std::integral_constant<int, 0x3>{}); break;
@@ -516,9 +513,9 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
             // allocator from shuffling the in-flight fragments of the other waves at the join)
 #pragma unroll
             for (int k12 = 0; k12 < 6; ++k12)
-                w4[k12] = ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
+                w4[k12] = ld_w32(a.w.wqkvT32, roleO ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
             tokn = load_rows(tile + gridDim.x, xnq, daq);
-            if (!(MSST_B3_EXP & 64)) wgrad();
+            wgrad();
             STAMP(6);
             bar3();   // B3
             STAMP(7);
@@ -530,7 +527,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
                 c4[0] = zero16(); c4[1] = zero16();
                 s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
-                if (!(MSST_B3_EXP & 32)) swpipe<12, MSST_B3_D4>(
+                swpipe<12, MSST_B3_D4>(
                     [&](int k12) {
                         const int which = k12 >> 2, ks = k12 & 3;
                         const int reg = which == 0 ? R3_K : which == 1 ? R3_Q : R3_DO;
@@ -541,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void block_bwd_attn_r3_kernel(AttnBwdArgs a
                         c4[0] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][0], c4[0]);
                         c4[1] = mma32(w4[k12 % 6], fb4[k12 % (MSST_B3_D4 + 1)][1], c4[1]);
                         if (k12 < 6)
-                            w4[k12] = ld_w32(a.w.wqkvT32, (MSST_B3_EXP & 1) ? 0 : f4_0 + ((k12 + 6) >> 2) * (inner >> 4) + ((k12 + 6) & 3), l16);
+                            w4[k12] = ld_w32(a.w.wqkvT32, f4_0 + ((k12 + 6) >> 2) * (inner >> 4) + ((k12 + 6) & 3), l16);
                         if (k12 == MSST_B3_W1AT) load_w1();   // the next tile's phase-1 weights, behind this phase's last weight request
                     });
                 const unsigned L9 = R3_OUT + l31 * 192 + (fz2(l31) << 4) + 8 * hi + 64 * wave;

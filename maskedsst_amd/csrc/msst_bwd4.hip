@@ -34,12 +34,11 @@
 #ifndef MSST_B3_W1AT
 #define MSST_B3_W1AT 8   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
 #endif
-#ifndef MSST_B3_EXP
-#define MSST_B3_EXP 0   // timing experiments (wrong results): 1 = every phase-4 weight request reads fragment 0, 2 = same for phase 1, 4 = every row
-                        // request reads token 0, 16 = no softmax phase, 32 = no phase 4, 64 = no weight-gradient GEMM, 256 = no barriers, 1024 = no copy-out
-#endif
 #ifndef MSST_B4_HASH_P1
 #define MSST_B4_HASH_P1 1   // the attention-probability dropout hash of all four key tiles is issued at the top of the softmax phase (0: per key tile, behind the softmax)
+#endif
+#ifndef MSST_B4_SPLIT
+#define MSST_B4_SPLIT 3   // 1: phase 1, 2: phase 3 -- half of a GEMM phase's C tiles first, their conversion + LDS stores between the MFMAs of the other half
 #endif
 #ifndef MSST_B4_LAG
 #define MSST_B4_LAG 2   // barriers head B runs behind head A (1 or 2; 3 would need a second OUT buffer)
@@ -70,7 +69,7 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 constexpr int R4_ROWBUF = 24576, R4_DA = 12288;
 constexpr int R4_G0 = 49152, R4_GSZ = 49152;
 constexpr int R3_Q = 0, R3_K = 8192, R3_DO = 16384, R3_V = 24576, R3_P = 32768, R3_DS = 40960;
-constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SEQ = 160000, R4_SEQO = 160272, R4_QT = 160272 + 272, R4_SMEM = R4_QT + 16;   // row map [64], sequence bases [65] x 2, tile ring [4]
+constexpr int R4_OUT = 147456, R4_MAP = 159744, R4_SEQ = 160000, R4_SEQO = 160272, R4_QT = 160272 + 272, R4_LSE = R4_QT + 16, R4_SMEM = R4_LSE + 1024;   // row map [64], sequence bases [65] x 2, tile ring [4], saved softmax statistics [tile parity][head][64] fp32
 
 // 16-byte slot s of row r lives at slot s ^ fz(r) (128-byte rows) / (s & ~3) | ((s & 3) ^ fz2(r)) (192-byte rows)
 __device__ __forceinline__ int fz(int r) { return (((r >> 1) & 1) << 2) | ((((r >> 2) ^ (r >> 3)) & 1) << 1) | ((r >> 3) & 1); }
@@ -138,7 +137,7 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, unsigned lds_ds
     asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs) : "memory", "m0");
 }
 __device__ __forceinline__ void bar3() {
-    if (MSST_B3_EXP & 256) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else lds_barrier();
+    lds_barrier();
 }
 __device__ __forceinline__ int launder3(int v) {
     asm volatile("" : "+v"(v));
@@ -153,7 +152,10 @@ __device__ __forceinline__ int launder3(int v) {
 // A draws two walk steps ahead (the atomic's round trip hides under phases 2 and 3) and publishes the tile through a four-entry LDS
 // ring; both heads read the same sequence, head B half a tile later.  The partition then depends on timing: gradients are no
 // longer bit-reproducible from run to run (summation order), which is why the static form stays the single-GPU default.
-template <bool DROP, bool QUEUE>
+// LSE: the forward saved log2 of every query's softmax denominator (BlockArgs.lse_out): the softmax phase computes p = exp2(s c - lse)
+// directly -- no row maximum, no row sum, no reciprocal, one cross-lane reduction (delta) instead of three.  The 64 values of a
+// (tile, head) ride in with the tile's rows: one 256-byte LDS-DMA per head into a buffer of the tile's parity.
+template <bool DROP, bool QUEUE, bool LSE>
 __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_char* const sm = (lds_char*)smem_raw;
@@ -196,6 +198,13 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     __syncthreads();
     // key tiles (16 keys each) that the 16 queries of this wave can see: those overlapping [first key of the first query's
     // sequence, last key of the last query's sequence]
+    int kvalid = 0;   // (LSE, short sequences) bit 4 t + r: key 16 t + 4 (lane / 16) + r belongs to the sequence of this lane's query 16 wave + lane % 16
+    if (LSE && L < 64) {
+        const int l_ = tid & 63, qr = 16 * wave + (l_ & 15);
+        const int qlo_ = qr - (int)(rowmap[qr] & 0xffffu), qhi_ = qlo_ + L;
+        for (int t = 0; t < 4; ++t)
+            for (int r = 0; r < 4; ++r) { const int key = 16 * t + 4 * (l_ >> 4) + r; kvalid |= (int)(key >= qlo_ && key < qhi_) << (4 * t + r); }
+    }
     unsigned need;
     {
         const int r0 = 16 * wave, r1 = 16 * wave + 15;
@@ -259,20 +268,29 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         rsx[jj] = (unsigned)(R4_SEQ + 4 * min((int)(sp >> 16), 64));
         rinv[jj] = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)s_ * 16u;
     }
+    const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.lse), 0, LSE ? (int)min((long)a.ntiles * H * 256, 0x7fffffffL) : 0, 0x00020000);
+    // (tile_, buf): the statistics of both heads of tile tile_ -> parity buffer of row buffer buf; wave Q of head A, one 4-byte piece per lane and head
+    auto dma_lse = [&](int tile_, int buf) {
+        if (!LSE || wv != 0) return;
+        const unsigned dst = (unsigned)(R4_LSE + (buf ? 512 : 0));
+        const unsigned voff = tile_ < a.ntiles ? (unsigned)(((tile_ * H + 2 * (int)blockIdx.y) * 64 + (launder3(tid) & 63)) * 4) : 0x80000000u;
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(dst), "v"(voff), "s"(lse_rs) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dword %1, %2, 0 offen lds" :: "s"(dst + 256), "v"(voff + 256u), "s"(lse_rs) : "memory", "m0");   // head B: the next 256 bytes
+    };
     auto dma_rows = [&](int buf) {
         int base[3];
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) base[jj] = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sm + rsx[jj]);
 #pragma unroll
         for (int jj = 0; jj < 3; ++jj) {
-            const int bs = (MSST_B3_EXP & 4) ? 0 : base[jj];
+            const int bs = base[jj];
             const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + rinv[jj];
             const unsigned dst = (unsigned)(buf + 3072 * wave + 1024 * jj);
             dma16(rows_x, dst, voff);
             dma16(rows_d, dst + R4_DA, voff);
         }
     };
-    if (!grp) { dma_rows(0); wait_vm0(); }
+    if (!grp) { dma_rows(0); dma_lse(QUEUE ? __builtin_amdgcn_readfirstlane(qt[0]) : (int)blockIdx.x, 0); wait_vm0(); }
     // copy-out of a finished tile (head B's waves; both heads' rows were summed in OUT by B's phase 4, published by barrier B4):
     // whole rows to the head pair's partial; buffer stores, a padding row gets an offset outside the descriptor and is dropped.
     unsigned cinv, csx;   // copy-out: thread <-> (row tid / 4, 48 bytes)
@@ -327,8 +345,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const int fi = 6 * dt + ks;
-                if (MSST_B4_WBASE && !(MSST_B3_EXP & 2)) w1[dt][ks] = ld_w32b(w1p, b1 + (fi >> 2) * 4096, (fi & 3) * 1024, l16);
-                else w1[dt][ks] = ld_w32(w1p, (MSST_B3_EXP & 2) ? 0 : f1_0 + fi, l16);
+                if (MSST_B4_WBASE) w1[dt][ks] = ld_w32b(w1p, b1 + (fi >> 2) * 4096, (fi & 3) * 1024, l16);
+                else w1[dt][ks] = ld_w32(w1p, f1_0 + fi, l16);
             }
     };
     load_w1();
@@ -367,6 +385,54 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) c[i][j] = zero16();
+#if MSST_B4_SPLIT & 1
+            // Row tile 0 first, then row tile 1 (twelve MFMAs each): the conversion + LDS stores of row tile 0's two C tiles and the
+            // softmax phase's lane addresses issue BETWEEN the MFMAs of row tile 1 (a 32x32x16 MFMA hides four single-issue
+            // instructions of its own wave) instead of all 64 values of the four C tiles behind the last MFMA, where both waves of
+            // the SIMD sit in their epilogues with the matrix pipe idle.
+            const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
+            auto ep1 = [&](int rt, int i) {
+                const int dt = i >> 2, q4 = i & 3;
+                lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
+            };
+            auto p2a_part = [&](int part) {
+                const int l = t_ & 63, g = l >> 4, c16 = l & 15, fzc = fz(c16);
+                if (part == 0) {
+                    p2a[0] = gb + c16 * 128 + ((g ^ fzc) << 4);          // (gb: no bits below 16 K, commutes with the XORs)
+                    p2a[1] = gb + c16 * 128 + (((4 + g) ^ fzc) << 4);
+                    asm volatile("" : "+v"(p2a[0]));
+                    asm volatile("" : "+v"(p2a[1]));
+                } else {
+                    p2a[2] = gb + (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);
+                    p2a[3] = (unsigned)(16 * wave + c16 - (int)(rowmap[16 * wave + c16] & 0xffffu));
+                    asm volatile("" : "+v"(p2a[2]));
+                    asm volatile("" : "+v"(p2a[3]));
+                }
+            };
+            s16x8 fb[4];   // LN1(x) / da fragments of step s = 6 rt + ks, three steps ahead of their MFMAs
+            auto rd1 = [&](int s_) {
+                const int rt = s_ / 6, ks = s_ % 6;
+                fb[s_ & 3] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + rt * 32 * 192);
+            };
+            rd1(0); rd1(1); rd1(2);
+#pragma unroll
+            for (int s_ = 0; s_ < 12; ++s_) {
+                const int rt = s_ / 6, ks = s_ % 6;
+                if (s_ + 3 < 12) rd1(s_ + 3);
+                MSST_SCHED_FENCE();
+                c[0][rt] = mma32(w1[0][ks], fb[s_ & 3], c[0][rt]);
+                if (s_ == 2) p2a_part(0);
+                if (s_ >= 7 && s_ <= 10) ep1(0, 2 * (s_ - 7));
+                MSST_SCHED_FENCE();
+                c[1][rt] = mma32(w1[1][ks], fb[s_ & 3], c[1][rt]);
+                if (s_ == 3) p2a_part(1);
+                if (s_ >= 7 && s_ <= 10) ep1(0, 2 * (s_ - 7) + 1);
+                MSST_SCHED_FENCE();
+            }
+            R4_STAMP(12);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ep1(1, i);
+#else
             s16x8 fb[3][2];   // LN1(x) / da fragments [slot][row tile], two k-steps ahead of their MFMAs
             swpipe<6, 2>(
                 [&](int ks) {
@@ -397,9 +463,10 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4)
                         lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
+#endif
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (!(MSST_B3_EXP & 1024) && !MSST_B4_COW && grp && ks != 0) copy_out();
+        if (!MSST_B4_COW && grp && ks != 0) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
@@ -430,6 +497,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int t = 0; t < 4; ++t) dm[t] = zero4();
             const float cs = a.scale * 1.44269504088896340736f;   // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e
+            float lse2 = 0.f;
+            if (LSE) lse2 = *reinterpret_cast<const __attribute__((address_space(3))) float*>(sm + R4_LSE + (xb ? 512 : 0) + grp * 256 + (16 * wave + c16) * 4);
             // The dropout hash needs no data: all four key tiles' keep bits first, while the phase's operand reads are in flight,
             // instead of 12 quarter-rate multiplies inside the dependent chain max -> exp -> sum -> P.  (Issued under phase 1's MFMAs
             // -- the VALU is idle there too -- it cost 2 %: phase 1 is on the critical path of its barrier interval.)
@@ -482,6 +551,21 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
                         for (int t = 0; t < 4; ++t) if (on(t)) dp[t] = P::mma(fv[ks2][t], fdo[ks2], dp[t]);   // C[i = key][j = query]
                 }
+                if (LSE) {
+                    // p = exp2(s c - lse): the statistics of the forward's own softmax of this (tile, head, query) -- the rows, weights and
+                    // rounding points of q / k are the forward's, so the recomputed scores differ from the ones it normalised by fp32
+                    // summation order only (a flipped bf16 rounding of q or k now and then: sum p = 1 to ~1e-3, the kernels' bf16 level)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        if (!on(t)) continue;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(fmaf(pr[t][r], cs, -lse2));
+                            // keys outside the query's own sequence: bit 4 t + r of the lane's (tile invariant) validity mask, as 0 / ~0
+                            pr[t][r] = MASKED ? __int_as_float(__float_as_int(e) & __builtin_amdgcn_sbfe(kvalid, 4 * t + r, 1)) : e;
+                        }
+                    }
+                } else {
                 float mx = -INFINITY;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -507,9 +591,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 sum = colgroup_sum(sum);
                 const float inv = __builtin_amdgcn_rcpf(sum);
 #pragma unroll
+                for (int t = 0; t < 4; ++t) if (on(t)) pr[t] = pr[t] * inv;
+                }
+#pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     if (!on(t)) { lds_w64(sm, R3_P + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
-                    pr[t] = pr[t] * inv;
                     f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                     if (DROP) {
                         if (!MSST_B4_HASH_P1) {
@@ -545,7 +631,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
             };
-            if (!(MSST_B3_EXP & 16)) {
+            {
                 if (L == 64) softmax_phase(std::integral_constant<int, -1>{});
                 else switch (need) {   // (wave uniform, tile invariant)
                     case 0x3: softmax_phase(std::integral_constant<int, 0x3>{}); break;
@@ -581,6 +667,77 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) c[ii][j] = zero16();
+            s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
+#if MSST_B4_SPLIT & 2
+            // d tile 0 first, then d tile 1 (eight MFMAs each): the conversions of d tile 0's C tiles -- the weight-gradient GEMM's A
+            // operand and the dq | dk | dv rows of phase 4 -- and their LDS stores issue between the MFMAs of d tile 1.  The stores go
+            // over the tile this wave reads as its second operand: every read of it is issued (pass 0) before the first store; a
+            // wave's LDS instructions execute in order.  One straight-line instance per role (Q: path X + stores, O: path X, K / V:
+            // path Y + stores) instead of a role branch per k-step.
+            s16x8 fb0[4];   // second operand, d tile 0: requested before barrier B2 (complete since barrier B1)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) fb0[kk] = lds_tr2(sm, p3_a2 + tr[0][0] + 2048 * kk, p3_a2 + tr[0][1] + 2048 * kk);
+            R4_STAMP(3);
+            bar3();   // B2
+            R4_STAMP(4);
+            if (!grp) { dma_rows(R4_ROWBUF - xb); dma_lse(QUEUE ? __builtin_amdgcn_readfirstlane(qt[(ks + 1) & 3]) : tile + (int)gridDim.x, R4_ROWBUF - xb); }
+            B4_PRIO(3);
+            auto phase3 = [&](auto role_tag) {
+                constexpr int ROLE = decltype(role_tag)::value;   // 0: Q, 1: O, 2: K / V
+                constexpr bool PX = ROLE < 2, WR = ROLE != 1;
+                s16x8 fa[4][2], fb1[4];
+                auto issue_a = [&](int kk) {
+                    if (PX) {
+                        fa[kk][0] = lds_r128(sm, a1 ^ (kk << 5));
+                        fa[kk][1] = lds_r128(sm, (a1 ^ (kk << 5)) + 4096);
+                    } else {
+                        fa[kk][0] = lds_tr2(sm, p3_a1 + tr[0][0] + 2048 * kk, p3_a1 + tr[0][1] + 2048 * kk);
+                        fa[kk][1] = lds_tr2(sm, p3_a1 + tr[1][0] + 2048 * kk, p3_a1 + tr[1][1] + 2048 * kk);
+                    }
+                };
+                const unsigned L7 = p3_a2 + l31 * 128 + (fz(l31) << 4) + 8 * hi;
+                s16x4 q0[2][4];   // bf16 of d tile 0's C tiles [row tile][4 registers]
+                auto ep3 = [&](int ct, int q4) {
+                    q0[ct][q4] = pk4(c[ct][0], q4);
+                    asm volatile("" : "+v"(q0[ct][q4]));   // (converted HERE, between the MFMAs: without stores -- wave O -- the compiler sinks the conversions behind the last one)
+                    if (WR) lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)), q0[ct][q4]);
+                };
+                issue_a(0); issue_a(1);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    const int dt = st >> 2, kk = st & 3;
+                    if (st + 2 < 4) issue_a(st + 2);
+                    if (st < 4) fb1[st] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * st, p3_a2 + tr[1][1] + 2048 * st);
+                    MSST_SCHED_FENCE();
+                    c[0][dt] = mma32(fa[kk][0], dt ? fb1[kk] : fb0[kk], c[0][dt]);
+                    if (dt) ep3(kk >> 1, 2 * (kk & 1));
+                    MSST_SCHED_FENCE();
+                    c[1][dt] = mma32(fa[kk][1], dt ? fb1[kk] : fb0[kk], c[1][dt]);
+                    if (dt) ep3(kk >> 1, 2 * (kk & 1) + 1);
+                    MSST_SCHED_FENCE();
+                }
+                R4_STAMP(11);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s16x8 r;
+                    const s16x4 lo = q0[kk >> 1][2 * (kk & 1)], hi4 = q0[kk >> 1][2 * (kk & 1) + 1];
+                    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+                    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+                    pa[0][kk] = r;
+                    pa[1][kk] = pk8(c[kk >> 1][1], kk & 1);
+                }
+                if (WR) {
+#pragma unroll
+                    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+                            lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + 4096, pk4(c[ct][1], q4));
+                }
+            };
+            if (wave == 0) phase3(std::integral_constant<int, 0>{});
+            else if (wave == 3) phase3(std::integral_constant<int, 1>{});
+            else phase3(std::integral_constant<int, 2>{});
+#else
             constexpr int D3 = MSST_B3_D3A;
             s16x8 fa[D3 + 1][2], fb[D3 + 1][2];   // [slot][tile], D3 k-steps ahead
             auto issue_b = [&](int kk) {
@@ -601,7 +758,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             R4_STAMP(3);
             bar3();   // B2
             R4_STAMP(4);
-            if (!grp) dma_rows(R4_ROWBUF - xb);
+            if (!grp) { dma_rows(R4_ROWBUF - xb); dma_lse(QUEUE ? __builtin_amdgcn_readfirstlane(qt[(ks + 1) & 3]) : tile + (int)gridDim.x, R4_ROWBUF - xb); }
             B4_PRIO(3);
 #pragma unroll
             for (int kk = 0; kk < D3; ++kk) issue_a(kk);
@@ -616,11 +773,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 MSST_SCHED_FENCE();
             }
             R4_STAMP(11);
-            s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) pa[dt][kk] = pk8(c[kk >> 1][dt], kk & 1);
+#endif
             // transposed 32-column fragment of a 96-wide tile in the C-layout row order: k row = 16 kk + 8 a + 4 hi + i / 4
             const unsigned L4 = (4 * hi + (i >> 2)) * 192 + (((2 * u + b) ^ hi) << 4) + 8 * (i & 1);
             unsigned tx[2];
@@ -639,6 +796,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         G[1][mt] = mma32(pa[1][kk], fx[st % (MSST_B3_D3B + 1)], G[1][mt]);
                     });
             };
+#if !(MSST_B4_SPLIT & 2)
             // dq | dk | dv also go to LDS, transposed ([d][row]), over the tile only this wave read above (k | q | dO)
             if (!roleO) {
                 const unsigned L7 = p3_a2 + l31 * 128 + (fz(l31) << 4) + 8 * hi;
@@ -650,6 +808,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         for (int q4 = 0; q4 < 4; ++q4)
                             lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + dt * 4096, pk4(c[ct][dt], q4));
             }
+#endif
             // requests of the weight-gradient GEMM's shadow: the first phase-4 weight fragments (waves Q, K, V), the next tile's rows
             const int l16 = l * 16;
             // (wave O, which has no phase 4, requests one hot fragment six times: a definition on every path keeps the register
@@ -657,21 +816,21 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // phase-4 fragment k12 = (which, ks): base of `which` (one SGPR each) + 1024 ks in the offset field
             const int b4 = launder_s(roleO ? 0 : f4_0 * 1024), b4s = launder_s(roleO ? 0 : (inner >> 4) * 1024);
             auto ld_w4 = [&](int k12) -> s16x8 {
-                if (MSST_B4_WBASE && !(MSST_B3_EXP & 1)) return ld_w32b(a.w.wqkvT32, b4 + (k12 >> 2) * b4s, (k12 & 3) * 1024, l16);
-                return ld_w32(a.w.wqkvT32, ((MSST_B3_EXP & 1) || roleO) ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
+                if (MSST_B4_WBASE) return ld_w32b(a.w.wqkvT32, b4 + (k12 >> 2) * b4s, (k12 & 3) * 1024, l16);
+                return ld_w32(a.w.wqkvT32, roleO ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
             };
 #pragma unroll
             for (int k12 = 0; k12 < MSST_B3_W4; ++k12) w4[k12] = ld_w4(k12);
             // copy-out of the tile of the walk step before (complete since barrier B2: head B's phase 4 ran two intervals behind)
-            if (MSST_B4_COW == 1 && !(MSST_B3_EXP & 1024) && wv == 3 && ks != 0) copy_out_wave();
-            if (MSST_B4_COW == 2 && !(MSST_B3_EXP & 1024) && !grp && ks != 0) copy_out();   // (2: all four waves of head A, a quarter each)
+            if (MSST_B4_COW == 1 && wv == 3 && ks != 0) copy_out_wave();
+            if (MSST_B4_COW == 2 && !grp && ks != 0) copy_out();   // (2: all four waves of head A, a quarter each)
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
             B4_PRIO(4);
             // the weight-gradient GEMM runs BEHIND barrier B3 (the rows it reads stay put: the next tile's go to the other row
             // buffer): phases 1 | 3 and 2 | 4 of the two heads, which share the barrier intervals, are then of equal length
-            if (!(MSST_B3_EXP & 64)) wgrad();
+            wgrad();
             R4_STAMP(9);
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
             if (roleO) {
@@ -681,7 +840,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
                 c4[0] = zero16(); c4[1] = zero16();
                 s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
-                if (!(MSST_B3_EXP & 32)) swpipe<12, MSST_B3_D4>(
+                swpipe<12, MSST_B3_D4>(
                     [&](int k12) {
                         const int which = k12 >> 2, ks = k12 & 3;
                         const int reg = gb + (which == 0 ? R3_K : which == 1 ? R3_Q : R3_DO);
@@ -728,7 +887,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #ifndef MSST_B4_VMW
 #define MSST_B4_VMW 0    // (12 measured 526.9 / 527.4 vs 526.9 / 531.2 us: nothing to gain, and the count is an invariant to maintain)
 #endif
-            if (!grp) { if (MSST_B4_VMW == 12 && !(MSST_B3_EXP & 2)) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vm0(); }
+            if (!grp) { if (MSST_B4_VMW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vm0(); }
         }
         R4_STAMP(7);
         bar3();   // B4
@@ -764,17 +923,20 @@ int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st) {
     if (!a.xn || !a.dab || !a.w.wqkv32 || !a.w.woutT32 || !a.w.wqkvT32 || nchunk < 1 || nchunk > a.ntiles) return MSST_ERR_BADARG;
     if (a.ntok * 192 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit row offsets of the copy-out descriptor
     typedef void (*kern_t)(AttnBwdArgs);
-    const kern_t kerns[4] = {&block_bwd_attn_r4_kernel<false, false>, &block_bwd_attn_r4_kernel<true, false>,
-                             &block_bwd_attn_r4_kernel<false, true>, &block_bwd_attn_r4_kernel<true, true>};
+    const kern_t kerns[8] = {&block_bwd_attn_r4_kernel<false, false, false>, &block_bwd_attn_r4_kernel<true, false, false>,
+                             &block_bwd_attn_r4_kernel<false, true, false>, &block_bwd_attn_r4_kernel<true, true, false>,
+                             &block_bwd_attn_r4_kernel<false, false, true>, &block_bwd_attn_r4_kernel<true, false, true>,
+                             &block_bwd_attn_r4_kernel<false, true, true>, &block_bwd_attn_r4_kernel<true, true, true>};
+    if (a.lse && (long)a.ntiles * a.H * 256 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit offsets of the statistics' descriptor
     if (!attr_set) {
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 8; ++i) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, R4_SMEM);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.queue ? 2 : 0)], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
+    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.queue ? 2 : 0) + (a.lse ? 4 : 0)], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
     return (int)hipGetLastError();
 }
 

@@ -43,9 +43,6 @@
 #ifndef MSST_B5_PRIO
 #define MSST_B5_PRIO 0   // 1: the M waves (the critical chain) run at s_setprio 1 against the L wave that shares their SIMD
 #endif
-#ifndef MSST_B5_EXP
-#define MSST_B5_EXP 0   // timing experiments (wrong results): 1 = L waves read tile 0 only, 2 = no dx1 / dab stores, 4 = M waves skip the dW phase
-#endif
 
 #ifdef MSST_STAMPS
 #define B5_STAMP(i) do { if (stamp_on) a.stamps[16 * wave + (i)] = __builtin_readcyclecounter(); } while (0)
@@ -157,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         const int pstride = (int)(a.ntok * 192);   // bytes between partial buffers (launcher: nparts * ntok * 192 < 2^31)
         auto issue = [&](int k, int ps0, int ps1) {
             const bool live = valid_step(k);
-            const int tile_ = (MSST_B5_EXP & 1) ? (int)blockIdx.x : live ? tile_at(k) : 0;
+            const int tile_ = live ? tile_at(k) : 0;
 #pragma unroll
             for (int ps = ps0; ps < ps1; ++ps) {
                 const int tok = tile_ * 64 + lw * 16 + ps * 8 + r8;
@@ -266,7 +263,6 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         // the M waves left the fp32 rows in sm.out; they leave the CU as contiguous 1 KB per wave-instruction (the tile is 24 KB /
         // 12 KB of consecutive addresses), not as the 64-byte pieces of the MFMA C layout
         auto writeout = [&](int k) {
-            if (MSST_B5_EXP & 2) return;
             const int tile_ = tile_at(k);
             const long tok0 = (long)tile_ * 64;
             const int li = lw * 64 + l;
@@ -507,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
         request_rows(k + 1);
 #endif
         // ---------------- phase 2: weight grads over the 64 rows of the tile ----------------
-        if (!(MSST_B5_EXP & 4)) {
+        {
 #pragma unroll
         for (int k0 = 0; k0 < 64; k0 += KS) {
             const frag ah = P::ld_ks(&sm.dhp[k0][wave * 16], LDH);  // A[i = n][k = row]

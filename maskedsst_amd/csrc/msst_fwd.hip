@@ -909,15 +909,17 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
         }
         int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
         if (grid > ncu) grid = ncu;
-        // default: the role-split kernel (msst_fwd3.hip: attention waves + row-local waves, phases of adjacent tiles overlapped);
-        // dbg 256 (MSST_KERNEL_FWD_HW): the round-1..3 kernel, all eight waves in lockstep
-        if (!(a.dbg & 256)) return launch_block_fwd_rs(a, grid, st);
-        return launch_block_fwd_hw(a, grid, st);
+        // the role-split kernel (msst_fwd3.hip: attention waves + row-local waves, phases of adjacent tiles overlapped)
+        return launch_block_fwd_rs(a, grid, st);
     }
     // persistent grid: 2 workgroups per CU (LDS 50 KB, <= 256 VGPRs)
     int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
     if (grid > 512) grid = 512;
     return launch_block_fwd_bf16(a, grid, st);
+}
+
+bool block_fwd_writes_lse(const BlockArgs& a, int prec) {
+    return prec == MSST_PREC_BF16 && a.H == 8 && !(a.dbg & (16 | 64));   // exactly the condition under which launch_block_fwd picks launch_block_fwd_rs
 }
 
 bool block_fwd_writes_xn(const BlockArgs& a, int prec) {

@@ -18,7 +18,7 @@
 // Measured: 293 -> 256 us per launch (B = 256, EnMAP shape; 252-262 us for the spatial launches, 266-274 for the spectral ones).
 // What bounds it: the A wave is ONE in-order instruction stream per SIMD (11.7 k cycles per head alone: projections 3.1 k, their
 // weight stream 1.4 k, attention MFMAs 1.3 k, softmax arithmetic 1.2 k, packing / stores / barriers the rest) and every piece costs about
-// its own issue time (timing-only builds: MSST_F3_EXP); the R waves' path is 178 us on its own.  DESIGN.md section 5, LABNOTES.md round 4.
+// its own issue time (timing-only builds, round 4: LABNOTES.md); the R waves' path is 178 us on its own.  DESIGN.md section 5, LABNOTES.md round 4.
 //
 //   interval   A waves (tile k)                 R waves
 //   q0         round 0: projections, j = 0, 1   out-projection K half 1 of tile k-1 (O of round 1), bias / dropout / +x -> x1,
@@ -58,12 +58,6 @@
 #ifndef MSST_F3_LN1Q
 #define MSST_F3_LN1Q 3   // interval in which the R waves run LN1 of tile k + 1: 3 = at the end of q3 (rows requested in q2), 2 = at the end of q2 (rows
                          // requested at its start), the interval whose barrier the R waves otherwise sit out
-#endif
-#ifndef MSST_F3_EXP
-#define MSST_F3_EXP 0   // timing experiments (wrong results): 1 = R waves skip the MLP, 2 = R waves skip the out-projection, 4 = A waves skip the softmax arithmetic,
-                        // 8 = every q / k / v weight request reads the same two fragments, 16 = no q / k / v weight requests inside the walk at all,
-                        // 32 = (MSST_F3_KM) the R waves do not hash, 64 = a quarter of the projection MFMAs, 128 = half the attention MFMAs (and the
-                        // projections they no longer need), 256 = no projection MFMAs, 512 = no attention arithmetic at all
 #endif
 
 #ifdef MSST_STAMPS
@@ -130,10 +124,7 @@ __device__ __forceinline__ frag ld_wb3(const elem* w, int voff, int soff) {
     return __builtin_bit_cast(frag, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
 }
 __device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* wqkv, int H, int h, const int (&voff)[2], int hb, int HB, int l16) {
-    if (MSST_F3_EXP & 8) {   // timing experiment: every request reads the same two (hot) fragments
-        out[0] = P::ld_w(wqkv, 96, 0, 0);
-        out[1] = P::ld_w(wqkv, 96, 16, 0);
-    } else if (MSST_F3_WOFF) {
+    if (MSST_F3_WOFF) {
         if (pi < 12) {
             const int st = pi / 3, ks = pi % 3;
             const int o = hb + (st >> 1) * HB + (st & 1) * 6144 + ks * 1024;
@@ -283,12 +274,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    if (((MSST_F3_EXP & 64) && t > 0) || (MSST_F3_EXP & 256)) continue;   // (64: timing experiment, a quarter of the projection MFMAs; 256: none)
                                     ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
                                     cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
+                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
@@ -305,12 +295,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    if (((MSST_F3_EXP & 64) && t > 0) || (MSST_F3_EXP & 256)) continue;
                                     cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
                                     ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                if (!(MSST_F3_EXP & 16)) load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
+                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
@@ -339,11 +328,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     for (int u = 0; u < 2; ++u)
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
-                            if (!((NM[u] >> t) & 1u) || (MSST_F3_EXP & 512)) { s[u][t] = zero4(); continue; }   // (512: timing experiment, no attention arithmetic at all)
+                            if (!((NM[u] >> t) & 1u)) { s[u][t] = zero4(); continue; }
                             s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
-                            if (!(MSST_F3_EXP & 128)) s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);   // (128: timing experiment, half the attention MFMAs)
+                            s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);
                         }
-                    if (!(MSST_F3_EXP & (4 | 512))) {
+                    {
                         // bit position of key 16 t + 4 g + r inside its 32-bit half of a 64-bit row mask: 16 (t & 1) + 4 g + r
                         int lq = threadIdx.x & 63;
                         asm volatile("" : "+v"(lq));
@@ -415,7 +404,14 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                             }
 #endif
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(colgroup_sum(sum[u]));   // the dropout scale rides on the normalisation
+                        for (int u = 0; u < 2; ++u) {
+                            const float st = colgroup_sum(sum[u]);
+                            inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(st);   // the dropout scale rides on the normalisation
+                            // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head), written by
+                            // the sixteen lanes of lane group 0 (a query's value is replicated over the four groups)
+                            if (a.lse_out && sh0 == 0)
+                                a.lse_out[((long)tile * H + h) * 64 + (2 * jp + u) * 16 + cq] = mc[u] + __builtin_amdgcn_logf(st);
+                        }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             // site 1 (MSST_F3_KM: keep bits hashed by the R waves): same masks as drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g)
@@ -444,9 +440,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                         for (int dd = 0; dd < 4; ++dd) {
                             o[u][dd] = zero4();
-                            if (MSST_F3_EXP & 512) { o[u][dd] = __builtin_bit_cast(f32x4, vA[dd][0]) ; continue; }
                             if (NM[u] & 3u) o[u][dd] = P::mma(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
-                            if ((NM[u] & 12u) && !(MSST_F3_EXP & 128)) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
+                            if (NM[u] & 12u) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
                         }
                     }
                     // pack2(o[2u'], o[2u' + 1]) holds, in lane (c, g), the natural channels 32 u' + 8 g .. + 7 of query row 16 j + c
@@ -564,7 +559,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
             for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque3(mh) + i) * 16, (8 * rd + s8) * 32);
     };
     auto outproj = [&](int rd) {
-        if (MSST_F3_EXP & 2) return;
         F3_LANE();
         frag fo[4][2];   // O row fragments of a k-step, requested three k-steps ahead
         swpipe<8, 3>(
@@ -634,7 +628,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     };
     // MLP GEMM 1 + GELU: rows 32 rh .., hidden units 32 mh .. + 31 -> HB
     auto mlp1 = [&](int k) {
-        if (MSST_F3_EXP & 1) return;
         F3_LANE();
         f32x4 hh[2][2];
 #pragma unroll
@@ -669,7 +662,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     };
     // MLP GEMM 2 + bias, dropout, residual -> y
     auto mlp2 = [&](int k) {
-        if (MSST_F3_EXP & 1) return;
         F3_LANE();
         f32x4 yy[2][3];
 #pragma unroll
@@ -718,7 +710,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // keep masks of the attention-probability dropout of walk step k -> km[k & 1]: R lane rt hashes the 16 element groups of
     // (head, query row) = (2 part + rt / 128 ..., rt % 64): two rows per lane and tile, one per call (part = 0, 1)
     auto keep_masks = [&](int k, int part) {
-        if (!DROP || !MSST_F3_KM || k >= nmine || (MSST_F3_EXP & 32)) return;   // (32: timing experiment, masks left as they are)
+        if (!DROP || !MSST_F3_KM || k >= nmine) return;
         int rt = (int)threadIdx.x - 256;
         asm volatile("" : "+v"(rt));
         const int hq = part * 256 + rt, hh = hq >> 6, q = hq & 63;   // head 0..7, query row 0..63

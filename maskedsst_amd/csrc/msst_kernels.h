@@ -34,6 +34,8 @@ struct BlockArgs {
     float* x1;        // [tokens][96] mid-block residual (x + attn), saved for the backward; may be null
     int x1_bf16;      // MSST_X1_BF16: x1 holds bf16 (role-split forward only)
     void* xn_out;     // optional [tokens][96] bf16: LN1(x) exactly as the block used it, saved for the attention backward (head-per-wave kernel only)
+    float* lse_out;   // optional [ntiles][H][64] fp32: per (tile, head, row) log2 of the softmax denominator of the scaled scores, max folded in
+                      // (p = exp2(s scale log2 e - lse)): the attention backward then skips max / sum / 1 / x (role-split kernel only)
     TileMap tm;
     int ntiles, max_grid, H;
     float scale;      // dim_head^-0.5
@@ -101,6 +103,7 @@ struct AttnBwdArgs {
     unsigned long long* stamps;
     Drop drop;
     int* queue;       // optional (two-head kernel): one zeroed counter per head pair -> dynamic tile queue instead of the static partition
+    const float* lse; // optional (two-head kernel): [ntiles][H][64] saved by the forward (BlockArgs.lse_out)
 };
 
 struct Ln1BwdArgs {
@@ -139,7 +142,7 @@ struct TokBwdArgs {
 // ---- opt-in per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----
 enum KernelId {
     K_PREP = 0, K_TOK_FWD, K_BLOCK_FWD, K_HEAD_FWD, K_LOSS_REDUCE, K_HEAD_BWD, K_REDUCE, K_BWD_MLP, K_BWD_ATTN,
-    K_ATTN_REDUCE, K_BWD_LN1, K_TOK_BWD, K_POS_SPLIT, K_ADAMW, K_BWD_LN1MLP, K_COUNT
+    K_ATTN_REDUCE, K_BWD_LN1, K_TOK_BWD, K_POS_SPLIT, K_ADAMW, K_BWD_LN1MLP, K_LAYERNORM, K_COUNT
 };
 void prof_begin(int id, hipStream_t st);
 void prof_end(hipStream_t st);
@@ -208,10 +211,16 @@ int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, flo
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                  float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st);   // msst_opt.hip (occupancy probe)
-int launch_block_fwd_hw(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd2.hip (bf16, 8 heads; head per wave, lockstep phases)
 int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd3.hip (bf16, 8 heads; role split: the default)
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
 bool block_fwd_writes_xn(const BlockArgs& a, int prec);   // does the kernel launch_block_fwd selects honour a.xn_out?
+bool block_fwd_writes_lse(const BlockArgs& a, int prec);  // ... a.lse_out?  (the role-split kernel: bf16, 8 heads, no selection flags)
 int launch_head_fwd(const HeadArgs& a, float* loss, hipStream_t st);
+// msst_ln.hip: stand-alone LayerNorm over the last axis (D <= 128; D = 96 vectorised)
+int launch_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, long rows, int D,
+                         float eps, hipStream_t st);
+int layernorm_bwd_grid(long rows, int D);   // workgroups (= slab rows of 2 D floats) the backward launch uses
+int launch_layernorm_bwd(const float* x, const float* g, const float* dy, float* dx, float* slab, int grid, long rows, int D,
+                         float eps, hipStream_t st);
 
 }  // namespace msst

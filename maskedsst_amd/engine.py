@@ -32,8 +32,14 @@ def _prec_of(name):
 def _kernel_flags():
     """MSST_KERNEL_* selection flags (include/msst.h), read from the environment on the HOST side per call: the
     library itself never reads the environment.  MSST_DBG=16 selects the generic template kernels, 64 the 4-wave
-    forward; 0 (default) the tuned kernels."""
-    return (int(os.environ.get("MSST_DBG", "0")) & 0xffff) << 8
+    forward, 128 the one-head attention backward; 0 (default) the tuned kernels.  Only those selection bits pass (plus 8 and
+    the wave-select bits 0x300 of the -DMSST_STAMPS kernel-study builds): MSST_X1_BF16 / MSST_BWD_DEFER_REDUCE share the
+    field and are set by the engine's own logic, never from the environment."""
+    v = int(os.environ.get("MSST_DBG", "0"))
+    allowed = 16 | 64 | 128
+    if v & 8:
+        allowed |= 8 | 0x300
+    return (v & allowed) << 8
 
 
 def _stream():
@@ -105,6 +111,15 @@ class Engine:
             self.attn_chunks = self.default_attn_chunks(n)
         if "MSST_BWD_GRID" not in os.environ:
             self.grid_rows = total - n
+
+    def queue_capable(self):
+        """Will blocks_bwd run the kernels that can DRAW their tiles (msst_block_bwd_chain with a tile queue: the two-head attention
+        backward + the fused LN1 / MLP launch)?  The static part of blocks_bwd's `chain` predicate: bf16 tuned kernels, no kernel
+        selection flags, an even head count with at most four head pairs, chaining not switched off.  (fp32, odd or more than
+        eight heads, MSST_DBG flags, MSST_BWD_CHAIN=0 fall back to msst_block_bwd: full static grids.)"""
+        H = int(self.enc.heads)
+        return (self.prec == PREC_BF16 and _kernel_flags() == 0 and H % 2 == 0 and H // 2 <= 4
+                and os.environ.get("MSST_BWD_CHAIN", "1") != "0")
 
     def set_precision(self, name):
         prec = _prec_of(name)
@@ -188,8 +203,17 @@ class Engine:
     def prep_weights(self):
         """fp32 master weights -> operand layout (one launch); call after every parameter update"""
         self.ensure()
-        _lib.check(self.lib.msst_prep_weights(_p(self._jobs), self._njobs, self._maxel, self.prec, _stream()),
-                   "msst_prep_weights")
+        first = getattr(self, "_prep_flag", None) is None or self._prep_flag.device != self._jobs.device
+        if first:
+            self._prep_flag = torch.zeros(1, dtype=torch.int32, device=self._jobs.device)
+            self._prep_checked = None
+        _lib.check(self.lib.msst_prep_weights(_p(self._jobs), self._njobs, ctypes.sizeof(MsstPrepJob), self._maxel, self.prec,
+                                              _p(self._prep_flag), _stream()), "msst_prep_weights")
+        if self._prep_checked is not self._jobs:   # once per job table: did the kernel skip a malformed job? (one sync at setup)
+            bad = int(self._prep_flag.item())
+            if bad:
+                raise _lib.MsstError(f"msst_prep_weights skipped malformed jobs (flags {bad}): operand copies are incomplete")
+            self._prep_checked = self._jobs
 
     # ------------------------------------------------------------------ forward pieces
     def tokenize(self, img, mask_u8=None, with_pos=True, emb_drop=(0.0, 0)):
@@ -235,20 +259,26 @@ class Engine:
         # bf16 x1 rows (MSST_X1_BF16): only the role-split forward writes them -- bf16, 8 heads, no kernel-selection flags;
         # MSST_X1_BF16=0 keeps fp32 rows.  The x1 tensor's dtype tells the backward which kind it holds.
         x1_bf16 = (save and self.prec == PREC_BF16 and H == 8 and flags == 0 and os.environ.get("MSST_X1_BF16", "1") != "0")
+        want_lse = save and self.prec == PREC_BF16 and H == 8 and flags == 0 and os.environ.get("MSST_LSE", "1") != "0"
         for i, (sname, l) in enumerate(self._layers()):
             y = torch.empty_like(x)
             x1 = (torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if x1_bf16 else torch.empty_like(x)) if save else None
             # bf16: the block also saves LN1(x) as it used it (bf16 rows), if the selected kernel can; the attention backward
             # then skips its own LN1.  The buffer rides on the x1 tensor object so that every caller keeps its (acts, x1s) pair.
             xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (save and self.prec != PREC_F32) else None
-            wrote = ctypes.c_int(0)
             mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+            # ... and (role-split kernel) the softmax statistics of every (tile, head, row): MSST_LSE=0 keeps the backward's own softmax
+            lse = None
+            if xn is not None and want_lse:
+                lse = torch.empty(int(self.lib.msst_block_lse_floats(mode, B, S, N, H)), dtype=torch.float32, device=x.device)
+            wrote = ctypes.c_int(0)
             _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec | flags | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i, _p(xn), ctypes.byref(wrote),
-                                               _stream()),
+                                               self.prec | flags | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i, _p(xn), _p(lse),
+                                               ctypes.byref(wrote), _stream()),
                        "msst_block_fwd")
             if x1 is not None:
-                x1._msst_xn = xn if wrote.value else None
+                x1._msst_xn = xn if (wrote.value & _lib.SAVED_XN) else None
+                x1._msst_lse = lse if (wrote.value & _lib.SAVED_LSE) else None
             acts.append(y)
             x1s.append(x1)
             x = y
@@ -335,6 +365,7 @@ class Engine:
         layers = self._layers()
         flags = _kernel_flags()
         xns = [getattr(t, "_msst_xn", None) for t in x1s]
+        lses = [getattr(t, "_msst_lse", None) for t in x1s]
         x1_bf16 = len(x1s) > 0 and all(t.dtype == torch.bfloat16 for t in x1s)
         if not x1_bf16 and any(t.dtype != torch.float32 for t in x1s):
             raise ValueError("saved x1 rows of mixed dtypes")
@@ -379,7 +410,7 @@ class Engine:
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
                     _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab_i), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec | x1flag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(dab),
+                    B, S, N, H, self.prec | x1flag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab),
                     1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
                 if not defer:
@@ -404,7 +435,7 @@ class Engine:
                 ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
                 _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
                 self.prec | flags | x1flag,
-                drop[0], drop[1], i, _p(xns[i]), _p(dab), _stream()), "msst_block_bwd")
+                drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab), _stream()), "msst_block_bwd")
             g, other = other, g
             self._fire(f"{sname}.{l}")
         return g

@@ -214,8 +214,10 @@ def attach_data_parallel(model, group=None, bucket_bytes=4 << 20):
     # channel workgroup simply draws fewer tiles, so nothing has to be reserved (MSST_DP_RESERVE_CUS, default 0 now; the static
     # partition with 32 reserved CUs is MSST_DP_TILE_QUEUE=0 MSST_DP_RESERVE_CUS=32).  Cost: the gradients are no longer
     # bit-reproducible from run to run (fp32 summation order follows the draw order).
+    # The queue only exists on the chained bf16 path (Engine.queue_capable): an fp32 run, an odd head count, MSST_DBG kernel
+    # selections or MSST_BWD_CHAIN=0 fall back to msst_block_bwd with full static grids -- those keep round 3's reservation.
     if model.dp_world > 1 or os.environ.get("MSST_FORCE_DP", "0") == "1":
-        eng.tile_queue = os.environ.get("MSST_DP_TILE_QUEUE", "1") != "0"
+        eng.tile_queue = os.environ.get("MSST_DP_TILE_QUEUE", "1") != "0" and eng.queue_capable()
         reserve = int(os.environ.get("MSST_DP_RESERVE_CUS", "0" if eng.tile_queue else "32"))
         if reserve > 0:
             eng.reserve_cus(reserve)

@@ -44,6 +44,8 @@ class StandInLib:
     def __init__(self, eng, grads_by_flat_name):
         self.eng, self.grads = eng, grads_by_flat_name
         self.block_calls = []
+        self.filled = {}
+        self.chain_calls = 0
         self.layers = eng._layers()
         self.next_block = len(self.layers) - 1
 
@@ -57,11 +59,43 @@ class StandInLib:
         self._fill("to_pixels.")
         return 0
 
+    ATTN = ("ln1_g", "ln1_b", "wqkv", "wout", "bo")          # what the attention half + LN1 backward of a block write
+    MLP = ("ln2_g", "ln2_b", "w1", "b1", "w2", "b2")          # ... and its MLP half
+
+    def _fill_half(self, i, names):
+        sname, l = self.layers[i]
+        for n in names:
+            self._fill(f"{sname}.{l}.{n}")
+        self.filled.setdefault(f"{sname}.{l}", set()).add("attn" if names is self.ATTN else "mlp")
+
     def msst_block_bwd(self, *a):
         sname, l = self.layers[self.next_block]   # the engine walks the blocks in reverse
+        self._fill_half(self.next_block, self.ATTN)
+        self._fill_half(self.next_block, self.MLP)
         self.next_block -= 1
         self.block_calls.append(f"{sname}.{l}")
-        self._fill(f"{sname}.{l}.")
+        return 0
+
+    def msst_block_bwd_chain(self, *a):
+        """include/msst.h: the call for block i runs [its MLP half when `first`] -> its attention half -> its LN1 backward FUSED with
+        the MLP half of block i - 1 (w_prev): block i's gradients are complete when this call returns, the MLP-half gradients
+        of block i - 1 are written one call EARLY.  This is the orchestration data parallel actually uses (bf16)."""
+        (w, g, w_prev, g_prev, x, x1, x1_prev, dy, dx, dx1, part, slab, grid_rows, nchunk, mode, B, S, N, H, prec, p, seed,
+         layer, xn, lse, dab, first, queue, stream) = a
+        assert layer == self.next_block, (layer, self.next_block)
+        has_prev = bool(ctypes.cast(w_prev, ctypes.c_void_p).value)
+        assert has_prev == (layer > 0) and bool(first) == (layer == len(self.layers) - 1)
+        assert bool(queue.value) == bool(self.eng.tile_queue), "data parallel: the chained calls must carry the tile queue"
+        assert xn.value and dab.value
+        if first:
+            self._fill_half(layer, self.MLP)
+        self._fill_half(layer, self.ATTN)
+        if has_prev:
+            self._fill_half(layer - 1, self.MLP)
+        sname, l = self.layers[layer]
+        self.next_block -= 1
+        self.block_calls.append(f"{sname}.{l}")
+        self.chain_calls += 1
         return 0
 
     def msst_tokenize_bwd(self, *a):
@@ -73,20 +107,23 @@ class StandInLib:
         return b""
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, precision="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         import maskedsst_amd.engine as engine_mod
         from maskedsst_amd.optim import attach_data_parallel, dp_mean
-        model, params, x = build_product(CFG)           # identical on every rank (same seed)
+        model, params, x = build_product(CFG, precision=precision)   # identical on every rank (same seed)
         ocfg = oracle_cfg_from(CFG)
         eng = model.engine()
         eng._require_cuda = lambda t: None               # CPU tensors stand in for device memory in this test only
         engine_mod._stream = lambda: ctypes.c_void_p(0)
         red = attach_data_parallel(model, bucket_bytes=64 << 10)   # the product's own wiring: hook + rank + world
         assert (model.dp_rank, model.dp_world) == (rank, world)
+        chained = precision == "bf16"
+        # fp32 has no queued kernels: attach_data_parallel must keep the static partition with reserved CUs there
+        assert eng.tile_queue == chained and eng.queue_capable() == chained
         sent = []
         flush = red._flush
 
@@ -110,6 +147,17 @@ def _worker(rank, world, port, q):
         T, K = eng.S * eng.N, masks[1].shape[1]
         acts = [torch.zeros(b, T, 96) for _ in range(2 * CFG["depth"] + 1)]
         x1s = [torch.zeros(b, T, 96) for _ in range(2 * CFG["depth"])]
+        if chained:   # the bf16 forward leaves LN1(x) rows on the x1 tensors: what makes blocks_bwd take the chained path
+            for t in x1s:
+                t._msst_xn = torch.zeros(b, T, 96, dtype=torch.bfloat16)
+        # a block's bucket may only be announced when BOTH halves of its gradients have been written
+        announce = eng.bucket_hook
+
+        def checked_hook(name, start, end):
+            if name.startswith(("spatial.", "spectral.")):
+                assert lib.filled.get(name) == {"attn", "mlp"}, (name, lib.filled.get(name))
+            announce(name, start, end)
+        eng.bucket_hook = checked_hook
         from maskedsst_amd.masking import inverse_csr
         ptr, pos = inverse_csr(masks[1].numpy(), T)
         dy = eng.head_bwd(acts[-1], torch.zeros(b, K, eng.P), torch.from_numpy(ptr), torch.from_numpy(pos))
@@ -120,6 +168,7 @@ def _worker(rank, world, port, q):
         # the engine announced the buckets in backward-completion order, each exactly once
         L = CFG["depth"]
         assert lib.block_calls == [f"spectral.{l}" for l in reversed(range(L))] + [f"spatial.{l}" for l in reversed(range(L))]
+        assert lib.chain_calls == (2 * L if chained else 0)
         covered = sorted(sent)
         assert covered[0][0] == 0 and covered[-1][1] == eng.fp.n_trainable
         for (s0, e0), (s1, e1) in zip(covered, covered[1:]):
@@ -143,11 +192,14 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"], ids=["unchained-fp32", "chained-bf16-tile-queue"])
+def test_two_rank_gloo_matches_single_process(precision):
+    """fp32: msst_block_bwd per block (static grids, reserved CUs).  bf16: the orchestration data parallel really uses --
+    msst_block_bwd_chain with the tile queue, MLP-half gradients of block i - 1 written by the call for block i."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, precision)) for r in range(2)]
     for p in procs:
         p.start()
     loss_dp, flat, names, segs, nsent, lr = q.get(timeout=240)

@@ -385,3 +385,67 @@ def test_bf16_x1_rows(cfg, monkeypatch):
     # median 2.66e-3 -> 2.67e-3).  Bars at 3.5x measured.
     assert e_dx < 4e-3, e_dx
     assert not bad, bad
+
+
+LSE_CASES = [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4), dict(bands=30, depth=1, B=3, image_size=6, mask_patch_size=2),
+             dict(bands=200, depth=1, B=256)]
+
+
+@pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 777)], ids=["nodrop", "drop0.1"])
+@pytest.mark.parametrize("cfg", LSE_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_saved_softmax_statistics(cfg, drop, monkeypatch):
+    """Round 5: the role-split forward saves lse = log2 of every query's softmax denominator (exponent domain of the kernels,
+    max folded in) per (tile, head, row); the two-head attention backward then computes p = exp2(s c - lse) directly instead
+    of its own max / sum / reciprocal (reference softmax: vit_spatial_spectral.py:71-73).
+    (1) the saved values against a torch restatement from the saved LN1 rows and the bf16 weights the kernels used;
+    (2) the backward with the saved statistics against the backward that normalises by itself (MSST_LSE=0) on the same rows
+        and masks: same rounding points for q / k / v, p differs by the fp32 summation order of the two kernels' scores."""
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+
+    def run(flag):
+        monkeypatch.setenv("MSST_LSE", flag)
+        out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+        torch.manual_seed(11)
+        dy = torch.randn_like(out["enc_out"]) * 1e-3
+        eng.fp.grad.zero_()
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy, drop=drop)
+        torch.cuda.synchronize()
+        return out, dx0.clone(), eng.fp.grad.clone()
+
+    o1, dx1, g1 = run("1")
+    o0, dx0, g0 = run("0")
+    monkeypatch.delenv("MSST_LSE")
+    assert all(getattr(t, "_msst_lse", None) is not None for t in o1["x1s"]) and all(getattr(t, "_msst_lse", None) is None for t in o0["x1s"])
+    assert torch.equal(o1["enc_out"], o0["enc_out"])   # the forward's arithmetic does not change
+    # (1) block 0 (spatial): sequences = (b, c), 64 // N sequences per tile, rows in token order
+    H, S, N = eng.enc.heads, eng.S, eng.N
+    B = cfg["B"]
+    xn = o1["x1s"][0]._msst_xn.float().reshape(B * S, N, 96)
+    wq = params["encoder.spatial_spectral_transformer.1.layers.0.0.fn.to_qkv.weight"].cuda().to(torch.bfloat16).float()
+    qkv = (xn @ wq.t()).to(torch.bfloat16).float()
+    q, k = qkv[..., :H * 64].reshape(B * S, N, H, 64), qkv[..., H * 64:2 * H * 64].reshape(B * S, N, H, 64)
+    s = torch.einsum("bnhd,bmhd->bhnm", q, k) * (0.125 * 1.4426950408889634)
+    ref = torch.logsumexp(s * 0.6931471805599453, dim=-1) * 1.4426950408889634      # log2 sum 2^s, [B S, H, N]
+    lse = o1["x1s"][0]._msst_lse
+    TS = 64 // N
+    nseq = B * S
+    ntiles = (nseq + TS - 1) // TS
+    got = lse.reshape(ntiles, H, 64)[:, :, :TS * N].reshape(ntiles, H, TS, N).permute(0, 2, 1, 3).reshape(ntiles * TS, H, N)[:nseq]
+    err = float((got - ref).abs().max())
+    assert err < 2e-2, err      # bf16 q / k (three significant digits) in scores of magnitude ~1: measured ~4e-3
+    # (2)
+    e_dx = rel_l2(dx1, dx0)
+    worst, bad = 0.0, []
+    for name, p in eng.trainable():
+        b = eng.fp.view(name, g0)
+        if float(b.abs().max()) == 0.0:
+            continue
+        e = rel_l2(eng.fp.view(name, g1), b)
+        worst = max(worst, e)
+        if not e < 6.3e-3:
+            bad.append((name, e))
+    record("saved_softmax_statistics", cfg=cfg, drop=list(drop), lse_abs_err=err, dx=e_dx, worst_grad=worst)
+    assert e_dx < 1.5e-3, e_dx
+    assert not bad, bad

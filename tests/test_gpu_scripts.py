@@ -111,11 +111,16 @@ for step in range(3):
     g = model.engine().fp.grad[: model.engine().fp.n_trainable].clone()
     opt.step()
     torch.cuda.synchronize()
+    if os.environ.get("DP_CHILD_DUMP") == "1":
+        np.save(sys.argv[1] + f".g{step}.npy", g.cpu().numpy())
     rec.append(dict(loss=loss.item(), gsum=float(g.double().sum()), gabs=float(g.double().abs().sum()),
                     g_sha=__import__("hashlib").sha256(g.cpu().numpy().tobytes()).hexdigest()))
 eng = model.engine()
 base = eng.fp.grad.data_ptr()
-out = dict(rec=rec, n_trainable=eng.fp.n_trainable,
+if os.environ.get("DP_CHILD_DUMP") == "1":
+    np.save(sys.argv[1] + ".p.npy", eng.fp.flat.cpu().numpy())
+out = dict(rec=rec, n_trainable=eng.fp.n_trainable, tile_queue=bool(eng.tile_queue), queue_used=getattr(eng, "_queue_ws", None) is not None,
+           grid_rows=eng.grid_rows, attn_chunks=eng.attn_chunks,
            sent=[((p - base) // 4, n) for p, n in sent],
            p_sha=__import__("hashlib").sha256(eng.fp.flat.cpu().numpy().tobytes()).hexdigest())
 json.dump(out, open(sys.argv[1], "w"))
@@ -150,3 +155,48 @@ def test_dp_wiring_single_rank_rccl(tmp_path):
         assert ranges[0][0] == 0 and ranges[-1][1] == b["n_trainable"], ranges
         for (s0, e0), (s1, e1) in zip(ranges, ranges[1:]):
             assert e0 == s1, ranges
+
+
+def test_dp_default_as_a_whole_single_rank_rccl_with_tile_queue(tmp_path):
+    """The data-parallel DEFAULT configuration, all of it at once on the one GPU there is: MSST_FORCE_DP=1
+    under torch.distributed.run with nothing overridden -- attach_data_parallel selects the dynamic tile queue and reserves no
+    CUs; the queued two-head attention backward and the queued fused LN1 + MLP launch fire the bucket hooks; RCCL all-reduces
+    every bucket on the process group's stream while the backward goes on; FusedAdamW applies the 1 / world mean.  Three AdamW
+    steps against the static single-process run: the partition follows the draw order, so the comparison is at the fp32
+    summation-order tolerance of test_tile_queue_at_bench_batch, not bitwise."""
+    script = tmp_path / "dp_child.py"
+    script.write_text(DP_CHILD)
+    plain, forced = str(tmp_path / "plain.json"), str(tmp_path / "dpq.json")
+    run([sys.executable, str(script), plain], env={"DP_CHILD_DUMP": "1"})
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {"MSST_FORCE_DP": "1", "DP_CHILD_DUMP": "1"}
+    for k in ("MSST_DP_TILE_QUEUE", "MSST_DP_RESERVE_CUS", "MSST_TILE_QUEUE", "MSST_BWD_CHAIN", "MSST_DBG"):
+        assert k not in os.environ, k   # the DEFAULT is what is under test
+    run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+         "--master-port", str(port), str(script), forced], env=env)
+    a, b = json.load(open(plain)), json.load(open(forced))
+    assert b["tile_queue"] and b["queue_used"] and not a["tile_queue"] and not a["queue_used"]
+    assert (a["grid_rows"], a["attn_chunks"]) == (b["grid_rows"], b["attn_chunks"])   # nothing reserved
+    # every step's buckets tile the trainable range exactly once
+    per_step = len(b["sent"]) // 3
+    assert per_step >= 2 and per_step * 3 == len(b["sent"]) and not a["sent"]
+    for s in range(3):
+        ranges = sorted((o, o + n) for o, n in b["sent"][s * per_step:(s + 1) * per_step])
+        assert ranges[0][0] == 0 and ranges[-1][1] == b["n_trainable"], ranges
+        for (s0, e0), (s1, e1) in zip(ranges, ranges[1:]):
+            assert e0 == s1, ranges
+    for s in range(3):
+        ga, gb = np.load(plain + f".g{s}.npy").astype(np.float64), np.load(forced + f".g{s}.npy").astype(np.float64)
+        # step 0 starts from identical parameters: the loss is bit-identical (the forward has no queue), the gradient differs in
+        # summation order only; later steps compound that through AdamW's sign-like first steps (lr 0.008)
+        err = float(np.linalg.norm(ga - gb) / np.linalg.norm(ga))
+        lerr = abs(a["rec"][s]["loss"] - b["rec"][s]["loss"]) / abs(a["rec"][s]["loss"])
+        if s == 0:
+            assert lerr == 0.0 and err <= 3.2e-3, (lerr, err)
+        else:
+            assert lerr <= 2e-3 and err <= 0.1, (s, lerr, err)
+    pa, pb = np.load(plain + ".p.npy").astype(np.float64), np.load(forced + ".p.npy").astype(np.float64)
+    assert float(np.linalg.norm(pa - pb) / np.linalg.norm(pa)) <= 2e-3

@@ -194,7 +194,41 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(_lib.declared_symbols()), declared ^ set(_lib.declared_symbols())
     loaded = _lib.load()
-    assert loaded.msst_version() == 102
+    assert loaded.msst_version() == _lib.header_version() == int(re.search(r"#define MSST_VERSION (\d+)", hdr).group(1))
+
+
+def test_stale_or_lab_library_is_refused(tmp_path, monkeypatch):
+    """_lib.load() compares msst_version() with include/msst.h: a library of another header revision (the prebuilt .so
+    travels with the tree and the build is mtime based) and a kernel-study build (-DMSST_LAB, negative version) raise"""
+    from maskedsst_amd import _lib
+    real = _lib.header_version()
+    for fake, word in ((real + 1, "stale"), (-real, "MSST_LAB")):
+        h = tmp_path / f"msst_{fake}.h"
+        # the header the binding believes in differs from what the library was built from
+        h.write_text("#define MSST_VERSION %d\n" % abs(fake))
+        monkeypatch.setattr(_lib, "_lib", None)
+        if fake > 0:
+            monkeypatch.setattr(_lib, "HEADER_PATH", str(h))
+            with pytest.raises(_lib.MsstError, match="stale library"):
+                _lib.load()
+            monkeypatch.setattr(_lib, "HEADER_PATH", os.path.join(ROOT, "include", "msst.h"))
+        else:
+            class _Neg:
+                def __init__(self, lib): self._l = lib
+                def __getattr__(self, n): return getattr(self._l, n)
+            import ctypes
+            realcdll = ctypes.CDLL
+            def fake_cdll(path, *a, **k):
+                lib = realcdll(path, *a, **k)
+                w = _Neg(lib)
+                w.msst_version = lambda: -real
+                return w
+            monkeypatch.setattr(_lib.ctypes, "CDLL", fake_cdll)
+            with pytest.raises(_lib.MsstError, match="MSST_LAB"):
+                _lib.load()
+            monkeypatch.setattr(_lib.ctypes, "CDLL", realcdll)
+    monkeypatch.setattr(_lib, "_lib", None)
+    assert _lib.load().msst_version() == real
 
 
 def test_product_does_not_import_oracle():

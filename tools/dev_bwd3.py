@@ -182,7 +182,7 @@ def dump_stages(eng, cfg, x, masks):
         _lib.check(eng.lib.msst_block_bwd(
             ctypes.byref(eng._bw[i]), ctypes.byref(eng._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g_in), _p(other),
             _p(dx1), _p(part), _p(slab), eng.grid_rows, eng.attn_chunks, mode, B, S, N, H,
-            eng.prec | _kernel_flags(), 0.0, 0, i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
+            eng.prec | _kernel_flags() | (_lib.X1_BF16 if x1s[i].dtype == torch.bfloat16 else 0), 0.0, 0, i, _p(getattr(x1s[i], "_msst_xn", None)), _p(getattr(x1s[i], "_msst_lse", None)), _p(dab), _stream()), "msst_block_bwd")
         torch.cuda.synchronize()
         os.environ["MSST_DBG"] = "0"
         img = buf.cpu().numpy().view(np.uint8)

@@ -38,7 +38,7 @@ for i in (0, 1):
             _lib.check(eng.lib.msst_block_bwd(
                 ctypes.byref(eng._bw[i]), ctypes.byref(eng._bg[i]), _p(acts[i]), _p(x1s[i]), _p(dy), _p(other),
                 _p(dx1), _p(part), _p(slab), eng.grid_rows, eng.attn_chunks, mode, B, S, N, H,
-                eng.prec | _kernel_flags(), drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
+                eng.prec | _kernel_flags() | (_lib.X1_BF16 if x1s[i].dtype == torch.bfloat16 else 0), drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(getattr(x1s[i], "_msst_lse", None)), _p(dab), _stream()), "msst_block_bwd")
             torch.cuda.synchronize()
         s = buf.cpu().numpy()
         d = [int(s[IDX[k + 1]] - s[IDX[k]]) for k in range(len(IDX) - 1)]

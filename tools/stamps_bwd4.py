@@ -15,6 +15,7 @@ eng = model.engine()
 masks = model.draw_masks(cfg["B"])
 drop = (0.1, 5)
 out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+torch.cuda.synchronize(); print("forward done", flush=True)
 dy = torch.randn_like(out["enc_out"]) * 1e-3
 buf = torch.zeros(512, dtype=torch.int64, device="cuda")
 assert eng.lib.msst_debug_stamps(ctypes.c_void_p(buf.data_ptr())) == 0, "build with --stamps"
@@ -36,8 +37,8 @@ for i in (0, 1):
         _lib.check(eng.lib.msst_block_bwd(
             ctypes.byref(eng._bw[i]), ctypes.byref(eng._bg[i]), _p(acts[i]), _p(x1s[i]), _p(dy), _p(other),
             _p(dx1), _p(part), _p(slab), eng.grid_rows, eng.attn_chunks, mode, B, S, N, H,
-            eng.prec | _kernel_flags(), drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(dab), _stream()), "msst_block_bwd")
-        torch.cuda.synchronize()
+            eng.prec | _kernel_flags() | (_lib.X1_BF16 if x1s[i].dtype == torch.bfloat16 else 0), drop[0], drop[1], i, _p(getattr(x1s[i], "_msst_xn", None)), _p(getattr(x1s[i], "_msst_lse", None)), _p(dab), _stream()), "msst_block_bwd")
+        torch.cuda.synchronize(); print("bwd call done", i, rep, flush=True)
     s = buf.cpu().numpy()
     t0 = min(int(s[16 * w]) for w in range(8))
     for w in range(8):
