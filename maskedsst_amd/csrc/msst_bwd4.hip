@@ -40,6 +40,18 @@
 #ifndef MSST_B4_SPLIT
 #define MSST_B4_SPLIT 3   // 1: phase 1, 2: phase 3 -- half of a GEMM phase's C tiles first, their conversion + LDS stores between the MFMAs of the other half
 #endif
+#ifndef MSST_B4_DMDIRECT
+#define MSST_B4_DMDIRECT 1   // the dropout multipliers of the attention probabilities are produced where their hash is (top of the softmax phase)
+#endif
+#if defined(MSST_LAB) && !defined(MSST_LAB_EXP)
+#define MSST_LAB_EXP 0
+#endif
+#ifndef MSST_B4_ADDMFMA
+#define MSST_B4_ADDMFMA 1   // head B adds head A's staged d(LN1 out) rows through identity MFMAs in front of its phase 4 (0: read - widen - add - round behind it)
+#endif
+#ifndef MSST_B4_WGPRE
+#define MSST_B4_WGPRE 0   // steps (of 12) of the weight-gradient GEMM in front of barrier B3
+#endif
 #ifndef MSST_B4_LAG
 #define MSST_B4_LAG 2   // barriers head B runs behind head A (1 or 2; 3 would need a second OUT buffer)
 #endif
@@ -142,6 +154,20 @@ __device__ __forceinline__ void bar3() {
 __device__ __forceinline__ int launder3(int v) {
     asm volatile("" : "+v"(v));
     return v;
+}
+
+// k-step f of a 32 x 32 bf16 identity as an A operand fragment (32 rows x 16 k; lane = 32 (k / 8 % 2) + row, 8 consecutive k per
+// lane): element e of lane (row i, half hi) is 1.0 where 16 f + 8 hi + e == i.  Head B's phase 4 starts from head A's staged rows
+// through two such MFMAs per row tile -- C[m][row] = sum_k I[m][k] staged[row][k], exact -- instead of reading, widening and
+// adding them on the VALU behind its own MFMAs (MSST_B4_ADDMFMA).  Built on the VALU (a dozen instructions per fragment): as a
+// table in memory the two loads sink to their only use and the phase starts with an L2 round trip.
+__device__ __forceinline__ s16x8 ident32_frag(int f, int i, int hi) {
+    const int e = i - 16 * f - 8 * hi;                                  // 0 .. 7 where this lane holds the 1
+    const unsigned one = 0x3F80u << ((e & 1) << 4), d = (unsigned)(e >> 1);   // (e outside 0 .. 7: d matches no dword)
+    u32x4 w;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w[k] = d == (unsigned)k ? one : 0u;
+    return __builtin_bit_cast(s16x8, w);
 }
 
 }  // namespace
@@ -414,6 +440,12 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 const int rt = s_ / 6, ks = s_ % 6;
                 fb[s_ & 3] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + rt * 32 * 192);
             };
+#ifdef MSST_LAB
+            // kernel-study build only (msst_version() < 0, refused by maskedsst_amd/_lib.py): MSST_LAB_EXP & 1 = the q / k / v waves skip
+            // their projections (WRONG results: stale tiles) -- what any scheme that hands q / k / v to the backward could gain at most
+            if ((MSST_LAB_EXP & 1) && !roleO) { p2a_part(0); p2a_part(1); } else
+#endif
+            {
             rd1(0); rd1(1); rd1(2);
 #pragma unroll
             for (int s_ = 0; s_ < 12; ++s_) {
@@ -432,6 +464,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             R4_STAMP(12);
 #pragma unroll
             for (int i = 0; i < 8; ++i) ep1(1, i);
+            }
 #else
             s16x8 fb[3][2];   // LN1(x) / da fragments [slot][row tile], two k-steps ahead of their MFMAs
             swpipe<6, 2>(
@@ -497,6 +530,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int t = 0; t < 4; ++t) dm[t] = zero4();
             const float cs = a.scale * 1.44269504088896340736f;   // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e
+            int kv_ = kvalid;
+            asm volatile("" : "+v"(kv_));   // (opaque per tile: left visible, the sixteen bit tests are hoisted out of the walk as lane masks in 32 SGPRs, spilled, and re-read with two v_readlane per score)
             float lse2 = 0.f;
             if (LSE) lse2 = *reinterpret_cast<const __attribute__((address_space(3))) float*>(sm + R4_LSE + (xb ? 512 : 0) + grp * 256 + (16 * wave + c16) * 4);
             // The dropout hash needs no data: all four key tiles' keep bits first, while the phase's operand reads are in flight,
@@ -508,8 +543,17 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                 for (int t = 0; t < 4; ++t) {
                     unsigned ha, hb;
                     drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
+#if MSST_B4_DMDIRECT
+                    // the multipliers themselves (0 or 1 / (1 - p)), one compare + one select per score, instead of keep bits packed into
+                    // a word here and unpacked (and + compare + select per score) behind the softmax: ~70 instructions per wave and tile
+                    dm[t][0] = (ha << 16) >= t16 ? a.drop.scale : 0.f;
+                    dm[t][1] = ha >= t16 ? a.drop.scale : 0.f;
+                    dm[t][2] = (hb << 16) >= t16 ? a.drop.scale : 0.f;
+                    dm[t][3] = hb >= t16 ? a.drop.scale : 0.f;
+#else
                     keepm |= ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
                               ((unsigned)(hb >= t16) << 3)) << (4 * t);
+#endif
                 }
             }
             // NM: -1 = one 64-token sequence, nothing masked; > 0 = short sequences, the key tiles of this wave known at compile
@@ -562,7 +606,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         for (int r = 0; r < 4; ++r) {
                             const float e = __builtin_amdgcn_exp2f(fmaf(pr[t][r], cs, -lse2));
                             // keys outside the query's own sequence: bit 4 t + r of the lane's (tile invariant) validity mask, as 0 / ~0
-                            pr[t][r] = MASKED ? __int_as_float(__float_as_int(e) & __builtin_amdgcn_sbfe(kvalid, 4 * t + r, 1)) : e;
+                            if (MASKED) {
+                                int m_;   // (as inline asm: from the builtin the compiler makes v_and + v_cmp_ne + v_cndmask, three instructions per score)
+                                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m_) : "v"(kv_), "n"(4 * t + r));
+                                pr[t][r] = __int_as_float(__float_as_int(e) & m_);
+                            } else pr[t][r] = e;
                         }
                     }
                 } else {
@@ -605,8 +653,9 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                             keepm = ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
                                      ((unsigned)(hb >= t16) << 3)) << (4 * t);
                         }
+                        if (!(MSST_B4_DMDIRECT && MSST_B4_HASH_P1))
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) dm[t][r] = (keepm >> (4 * t + r)) & 1u ? a.drop.scale : 0.f;
+                            for (int r = 0; r < 4; ++r) dm[t][r] = (keepm >> (4 * t + r)) & 1u ? a.drop.scale : 0.f;
                         pd = pd * dm[t];
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
@@ -783,18 +832,22 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             unsigned tx[2];
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) tx[aa] = p3_x + (L4 ^ (aa << 5)) + 8 * aa * 192;
-            auto wgrad = [&]() {
-                s16x8 fx[MSST_B3_D3B + 1];   // step s = (kk, mt): transposed row fragment MSST_B3_D3B steps ahead
-                swpipe<12, MSST_B3_D3B>(
-                    [&](int st) {
-                        const int kk = st / 3, mt = st % 3;
-                        fx[st % (MSST_B3_D3B + 1)] = lds_tr2(sm, tx[0] + 3072 * kk + 64 * mt, tx[1] + 3072 * kk + 64 * mt);
-                    },
-                    [&](int st) {
-                        const int kk = st / 3, mt = st % 3;
-                        G[0][mt] = mma32(pa[0][kk], fx[st % (MSST_B3_D3B + 1)], G[0][mt]);
-                        G[1][mt] = mma32(pa[1][kk], fx[st % (MSST_B3_D3B + 1)], G[1][mt]);
-                    });
+            // steps [LO, HI) of the weight-gradient GEMM's twelve (kk, mt) steps
+            auto wgrad = [&](auto lo_c, auto hi_c) {
+                constexpr int LO = decltype(lo_c)::value, HI = decltype(hi_c)::value;
+                if constexpr (HI > LO) {
+                    s16x8 fx[MSST_B3_D3B + 1];   // step s = (kk, mt): transposed row fragment MSST_B3_D3B steps ahead
+                    swpipe<HI - LO, MSST_B3_D3B>(
+                        [&](int s0) {
+                            const int st = s0 + LO, kk = st / 3, mt = st % 3;
+                            fx[s0 % (MSST_B3_D3B + 1)] = lds_tr2(sm, tx[0] + 3072 * kk + 64 * mt, tx[1] + 3072 * kk + 64 * mt);
+                        },
+                        [&](int s0) {
+                            const int st = s0 + LO, kk = st / 3, mt = st % 3;
+                            G[0][mt] = mma32(pa[0][kk], fx[s0 % (MSST_B3_D3B + 1)], G[0][mt]);
+                            G[1][mt] = mma32(pa[1][kk], fx[s0 % (MSST_B3_D3B + 1)], G[1][mt]);
+                        });
+                }
             };
 #if !(MSST_B4_SPLIT & 2)
             // dq | dk | dv also go to LDS, transposed ([d][row]), over the tile only this wave read above (k | q | dO)
@@ -824,13 +877,16 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // copy-out of the tile of the walk step before (complete since barrier B2: head B's phase 4 ran two intervals behind)
             if (MSST_B4_COW == 1 && wv == 3 && ks != 0) copy_out_wave();
             if (MSST_B4_COW == 2 && !grp && ks != 0) copy_out();   // (2: all four waves of head A, a quarter each)
+            // MSST_B4_WGPRE of the weight-gradient GEMM's twelve steps run in FRONT of barrier B3 (round 5: with the forward's softmax
+            // statistics the softmax phase that shares the next interval is shorter than weight-gradient GEMM + phase 4)
+            wgrad(std::integral_constant<int, 0>{}, std::integral_constant<int, MSST_B4_WGPRE>{});
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
             B4_PRIO(4);
             // the weight-gradient GEMM runs BEHIND barrier B3 (the rows it reads stay put: the next tile's go to the other row
             // buffer): phases 1 | 3 and 2 | 4 of the two heads, which share the barrier intervals, are then of equal length
-            wgrad();
+            wgrad(std::integral_constant<int, MSST_B4_WGPRE>{}, std::integral_constant<int, 12>{});
             R4_STAMP(9);
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
             if (roleO) {
@@ -839,6 +895,23 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             } else {
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
                 c4[0] = zero16(); c4[1] = zero16();
+#if MSST_B4_ADDMFMA
+                if (grp) {   // head B: accumulate ONTO head A's rows (staged two intervals ago), exact: 1.0 x bf16 in fp32
+                    s16x8 fs[2][2], idf[2];
+#pragma unroll
+                    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+                        for (int f2 = 0; f2 < 2; ++f2)
+                            fs[rt][f2] = lds_r128(sm, R4_OUT + (32 * rt + l31) * 192 + ((4 * wave + ((2 * f2 + hi) ^ fz2(l31))) << 4));
+#pragma unroll
+                    for (int f2 = 0; f2 < 2; ++f2) idf[f2] = ident32_frag(f2, l31, hi);
+#pragma unroll
+                    for (int f2 = 0; f2 < 2; ++f2) {
+                        c4[0] = mma32(idf[f2], fs[0][f2], c4[0]);
+                        c4[1] = mma32(idf[f2], fs[1][f2], c4[1]);
+                    }
+                }
+#endif
                 s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
                 swpipe<12, MSST_B3_D4>(
                     [&](int k12) {
@@ -873,7 +946,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                             asm volatile("ds_pk_add_bf16 %0, %1\n\tds_pk_add_bf16 %0, %2 offset:4" :: "v"(la), "v"(w0), "v"(w1_) : "memory");
                             continue;
                         }
-                        if (grp) {
+                        if (grp && !MSST_B4_ADDMFMA) {
                             const s16x4 o4 = *reinterpret_cast<const lds_s16x4*>(sm + o);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) t4[e] += __builtin_bit_cast(float, (unsigned)(unsigned short)o4[e] << 16);

@@ -48,6 +48,12 @@
                        // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
                        // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
 #endif
+#ifndef MSST_F3_YSC1
+#define MSST_F3_YSC1 0   // 1: the block output rows leave with sc1 (write-through, the line is dropped from the XCD's L2): leaves the L2 to the x rows the residual add re-reads
+#endif
+#if defined(MSST_LAB) && !defined(MSST_LAB_X1OLD)
+#define MSST_LAB_X1OLD 0
+#endif
 #ifndef MSST_F3_KMQ
 #define MSST_F3_KMQ 1   // (MSST_F3_KM) where the R waves hash: 1 = at the END of q0 / q2, at priority 0 -- the intervals whose barrier the R waves otherwise
                         // sit out waiting for the A waves' projections; 0 = in q1 / q3 at the R waves' raised priority (the first version)
@@ -240,6 +246,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         // (pair p of a head always lives in slot p % NR: for pi >= 18 - NR the freed slots pi % NR run through 0 .. NR - 1 exactly once)
         auto next_pair = [](int pi) { return pi + NR < 18 ? pi + NR : pi % NR; };
         const int HB = H * 12288, l16 = l * 16;
+        const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc(a.lse_out, 0, a.lse_out ? (int)min((long)a.ntiles * H * 256, 0x7fffffffL) : 0, 0x00020000);
 #pragma unroll
         for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wqkv, H, wv, voff, wv * 12288, HB, l16);
 
@@ -407,10 +414,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                         for (int u = 0; u < 2; ++u) {
                             const float st = colgroup_sum(sum[u]);
                             inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(st);   // the dropout scale rides on the normalisation
-                            // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head), written by
-                            // the sixteen lanes of lane group 0 (a query's value is replicated over the four groups)
-                            if (a.lse_out && sh0 == 0)
-                                a.lse_out[((long)tile * H + h) * 64 + (2 * jp + u) * 16 + cq] = mc[u] + __builtin_amdgcn_logf(st);
+                            // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head).  One
+                            // buffer store, no branch: (tile, head) rides in the scalar offset, the query row in the lane offset; a query's
+                            // value is replicated over the four lane groups, which all write it (an out-of-range offset -- no buffer given:
+                            // zero records -- is dropped by the hardware)
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mc[u] + __builtin_amdgcn_logf(st)), lse_rs, cq * 4,
+                                                                  ((tile * H + h) * 64 + (2 * jp + u) * 16) * 4, 0);
                         }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
@@ -531,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     f32x4 acc[2][3];
     f32x4 x1r[2][3];   // x1 of the owned rows / features of tile k - 1: in registers until the end of its MLP
     f32x4 xr[2][3];    // residual x values of the tile whose out-projection completes next
-    float mean_w[2], m2_w[2];
+    float mean_w[2], m2_w[2], mean_r[2] = {0.f, 0.f};
     // per-thread indices are re-derived from a laundered lane id inside every stage: derived once, the compiler hoists two dozen
     // lane-dependent addresses out of the walk, keeps them live across all stages and spills them (each reload carries a vmcnt(0)
     // that also waits for the weight fragments in flight)
@@ -590,10 +599,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 o4 = o4 + xr[jj][i];
                 x1r[jj][i] = o4;
                 s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
-                if (a.x1 && tok >= 0) {   // saved for the MLP-half backward: fp32, or (MSST_X1_BF16) bf16 -- a quarter of this kernel's writes less
-                    if (a.x1_bf16) *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(o4);
-                    else *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
-                }
+                // saved for the MLP-half backward: fp32 here; the bf16 form (MSST_X1_BF16: a quarter of this kernel's writes less) leaves
+                // in ln2(), CENTRED on the row mean that is only known there
+                if (a.x1 && tok >= 0 && !a.x1_bf16) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+#ifdef MSST_LAB
+                if (MSST_LAB_X1OLD && a.x1 && tok >= 0 && a.x1_bf16) *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(o4);   // (round 4's uncentred rows, for timing only)
+#endif
             }
             const float mw = colgroup_sum(s1) * (1.f / 48.f);
             float m2 = 0.f;
@@ -623,6 +634,31 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) n4[r] = (x1r[jj][i][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
                 *reinterpret_cast<s16x4*>(&sm.xn2[32 * rh + 16 * jj + c3][m0]) = f2bf4(n4);
+            }
+            mean_r[jj] = mean;
+        }
+    };
+    // MSST_X1_BF16: the backward reads the saved mid-residual rows only through LN2 (statistics, xhat), which does not see a per-row
+    // constant -- so the bf16 rows are bf16(x1 - row mean): their rounding error is relative to the row's spread, not to its offset
+    // (a trained residual stream with |mean| >> std would otherwise lose its LN2 statistics to the rounding).  The mean is known
+    // since ln2() (q1, where the A waves wait for the R waves); the stores leave in q2, where the R waves have slack.
+    auto store_x1_bf16 = [&](int k) {
+        if (!(a.x1 && a.x1_bf16)) return;
+#ifdef MSST_LAB
+        if (MSST_LAB_X1OLD) return;
+#endif
+        F3_LANE();
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj) {
+            const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
+            if (tok < 0) continue;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int m0 = (3 * mh + i) * 16 + 4 * g3;
+                f32x4 c4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) c4[r] = x1r[jj][i][r] - mean_r[jj];
+                *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(c4);
             }
         }
     };
@@ -695,7 +731,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     for (int r = 0; r < 4; ++r) o4[r] = yy[jj][jm][r] + lnp[480 + m0 + r];
                     if (DROP) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                     o4 = o4 + x1r[jj][jm];
-                    *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+                    if (MSST_F3_YSC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(a.y + tok * 96 + m0), "v"(o4) : "memory");
+                    else *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
                 }
             }
         }
@@ -766,7 +803,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         if (MSST_F3_LN1Q == 2 && k + 1 < nmine) request_ln1(k + 1);
         if (have_cur) outproj(0);
         F3_STAMP(6);
-        if (have_prev) mlp1(k - 1);
+        if (have_prev) { store_x1_bf16(k - 1); mlp1(k - 1); }
         if (MSST_F3_LN1Q == 2 && k + 1 < nmine) ln1(k + 1);
         if (MSST_F3_LN1Q == 3 && k + 1 < nmine) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
         if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 1); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }

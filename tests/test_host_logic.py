@@ -392,3 +392,31 @@ def test_synthetic_cube_loader_contract():
         n += 1
     assert n == 4
     assert abs(float(ref.pool[:, :48].std()) - 1.0) < 0.02
+
+
+def test_strict_tier_trips_at_twice_the_baseline():
+    """tests/util.py::strict_violations (MSST_STRICT_PARITY=1): every row of the committed parity baseline is inside the tier of
+    itself, and the same row with every bf16-level error doubled is outside it (errors at the fp32 noise floor, < 1e-6, are
+    not held to a ratio)."""
+    import copy
+    import util
+    rows = copy.deepcopy(util._baseline())
+    assert len(rows) > 30
+    tripped = 0
+    for r in rows:
+        t = r.pop("test")
+        assert util.strict_violations(t, r) == [], (t, util.strict_violations(t, r))
+
+        def dbl(v):
+            if isinstance(v, float):
+                return 2.0 * v
+            if isinstance(v, dict):
+                return {k: dbl(x) for k, x in v.items()}
+            return v
+        big = any(isinstance(v, float) and v > 2e-6 for k, v in r.items() if util._is_err_key(k)) or \
+            any(isinstance(v, dict) and any(isinstance(x, float) and x > 2e-6 for x in v.values()) for k, v in r.items() if util._is_err_key(k))
+        r2 = {k: (dbl(v) if util._is_err_key(k) else v) for k, v in r.items()}
+        if big and t not in util.STRICT_EXEMPT:
+            assert util.strict_violations(t, r2), (t, r)
+            tripped += 1
+    assert tripped > 30

@@ -71,9 +71,16 @@ def _identity(row):
     return {k: v for k, v in row.items() if not isinstance(v, float) and not (isinstance(v, dict) and k != "cfg") and k not in ("worst_grad_name", "worst")}
 
 
+# comparisons of two summation orders of the SAME arithmetic: their size is decided by whether a last-bit difference flips a bf16
+# rounding somewhere (1e-7 for one input, 1e-4 for the next): not a measurement a ratio can be held against
+STRICT_EXEMPT = {"chained_backward_matches_unchained"}
+
+
 def strict_violations(test, kv, factor=STRICT_FACTOR, floor=1e-6):
     """[(key, measured, baseline)] of the recorded errors that exceed factor x the baseline row of the same test and identity
     (no such row: nothing to compare with -> [])."""
+    if test in STRICT_EXEMPT:
+        return []
     ident = json.loads(json.dumps(_identity(dict(test=test, **kv))))
     rows = [r for r in _baseline() if json.loads(json.dumps(_identity(r))) == ident]
     if not rows:
