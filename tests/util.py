@@ -47,7 +47,7 @@ def rel_l2(a, b):
 # ---- two assertion tiers for the bf16 kernels ----
 # hard tier: the bars written in the tests (3-4x the error measured on the device: they survive compiler / clock / box changes);
 # strict tier, MSST_STRICT_PARITY=1 (tools/final_prof.sh and __graft_entry__.smoke() set it): every error a test records must
-# also stay within STRICT_FACTOR x the value the SAME test recorded in the committed baseline (profiles/r04_parity_measured.jsonl,
+# also stay within STRICT_FACTOR x the value the SAME test recorded in the committed baseline (the newest profiles/rNN_parity_measured.jsonl,
 # or $MSST_PARITY_BASELINE), so that a 2x regression of a gradient error is seen by the builder before the driver's run.
 STRICT_FACTOR = 1.5
 _ERR_KEY = ("err", "dx", "worst_grad", "stage_l2", "one_minus_cos", "worst_slice", "worst_abs", "rel_dev")
@@ -61,7 +61,9 @@ def _is_err_key(k):
 def _baseline():
     global _baseline_rows
     if _baseline_rows is None:
-        path = os.environ.get("MSST_PARITY_BASELINE") or os.path.join(ROOT, "profiles", "r04_parity_measured.jsonl")
+        import glob
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_parity_measured.jsonl")))
+        path = os.environ.get("MSST_PARITY_BASELINE") or (newest[-1] if newest else "")
         _baseline_rows = [json.loads(l) for l in open(path) if l.strip()] if os.path.exists(path) else []
     return _baseline_rows
 

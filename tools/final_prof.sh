@@ -7,14 +7,15 @@ TAG="${1:?usage: final_prof.sh rNN}"
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 OUT=gpurun_out/final
 rm -rf "$OUT"; mkdir -p "$OUT"
-export MSST_ROUND="$TAG" MSST_RECORD=1
+export MSST_ROUND="$TAG" MSST_RECORD=1 MSST_STRICT_PARITY=1   # strict tier: every recorded error within 1.5x the committed baseline (tests/util.py)
 # parity measurements of the round (tests/util.py::record appends to gpurun_out/parity_$TAG.jsonl)
 rm -f "gpurun_out/parity_$TAG.jsonl"
 python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.txt || true; cat $OUT/gpu_tests.txt
 # box microbenchmark (MFMA / HBM / L2 / LDS access patterns)
+unset MSST_STRICT_PARITY
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/peak_microbench.hip -o /tmp/peak_microbench && /tmp/peak_microbench > $OUT/peak_microbench.json
 export TMPDIR=/tmp
-B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline"
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic"
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- $B > /dev/null 2>&1 || true
 done
@@ -28,35 +29,36 @@ find $OUT -name "*.csv" -size +512k -delete
 # the per-launch HBM traffic table bench.py quotes (roofline.traffic, hbm_bound_kernels) comes from these passes: write it in
 # place BEFORE the bench lines below are taken, so that the committed line and the committed table belong to the same kernels
 python3 tools/make_profiles.py "$TAG" --traffic-only
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.txt 2>&1 || true
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench.py --no-cpu-baseline --no-traffic > $OUT/bench_under_rocprof.txt 2>&1 || true
 find $OUT/stats -name "*kernel_trace.csv" -delete
 timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err || true
 tail -1 $OUT/bench_default.json | cut -c1-600
-timeout 600 python3 bench.py --no-cpu-baseline --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
+timeout 600 python3 bench.py --no-cpu-baseline --no-traffic --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
 # other configurations (parity-test shapes and the batch sweep), one line each
-( python3 bench.py --no-cpu-baseline --dropout 0 | tail -1
-  python3 bench.py --no-cpu-baseline --bands 50 | tail -1
-  python3 bench.py --no-cpu-baseline --batch 64 | tail -1
-  python3 bench.py --no-cpu-baseline --batch 1024 --steps 5 | tail -1
-  python3 bench.py --no-cpu-baseline --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null || true
+( python3 bench.py --no-cpu-baseline --no-traffic --dropout 0 | tail -1
+  python3 bench.py --no-cpu-baseline --no-traffic --bands 50 | tail -1
+  python3 bench.py --no-cpu-baseline --no-traffic --batch 64 | tail -1
+  python3 bench.py --no-cpu-baseline --no-traffic --batch 1024 --steps 5 | tail -1
+  python3 bench.py --no-cpu-baseline --no-traffic --precision fp32 --steps 3 --warmup 1 | tail -1 ) > $OUT/bench_other_configs.jsonl 2>/dev/null || true
 cut -c1-200 $OUT/bench_other_configs.jsonl
 # CU contention: the step with N occupancy-probe workgroups held on a side stream, default grid and the DP grid
 # static partition (single-GPU default), static partition on grids sized for 32 free CUs (round 3's DP choice; with and without a
 # probe), and the dynamic tile queue (round 4's DP choice: no reservation)
-( python3 bench.py --no-cpu-baseline --no-pipeline --no-profile | tail -1
-  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n | tail -1; done
-  python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief 1 --thief-us 1 --thief-reserve 32 | tail -1
-  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --thief-reserve 32 | tail -1; done
-  python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --tile-queue | tail -1
-  for n in 8 16 32 48; do python3 bench.py --no-cpu-baseline --no-pipeline --no-profile --cu-thief $n --tile-queue | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
+( python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n | tail -1; done
+  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief 1 --thief-us 1 --thief-reserve 32 | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n --thief-reserve 32 | tail -1; done
+  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --tile-queue | tail -1
+  for n in 8 16 32 48; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n --tile-queue | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
 python3 - << 'PY'
 import json
 for l in open("gpurun_out/final/cu_contention.jsonl"):
     d = json.loads(l); print(d.get("cu_thief"), d["ms_per_step"], d["value"])
 PY
 # data-parallel wiring on one GPU: a one-rank RCCL group, bucket hooks fired by the real backward (bench.py --force-dp)
-rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline > $OUT/dp_bench.txt 2>&1 || true
+rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic > $OUT/dp_bench.txt 2>&1 || true
 python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1 || true; cat $OUT/dp_overlap.txt
 find $OUT/dp -name "*.csv" -size +512k -delete
+hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gate_microbench.hip -o /tmp/gate_microbench && timeout 120 /tmp/gate_microbench > $OUT/gate_microbench.jsonl || true
 cp "gpurun_out/parity_$TAG.jsonl" $OUT/parity_measured.jsonl 2>/dev/null || true
 ls -la $OUT | head -40

@@ -20,7 +20,7 @@ def pmc(path, counter):
 fetch = pmc(os.path.join(SRC, "pmc_fetch.txt"), "FETCH_SIZE")
 write = pmc(os.path.join(SRC, "pmc_write.txt"), "WRITE_SIZE")
 # (pattern, bench.py kernel name): first match wins, the more specific pattern first
-short = [("block_fwd_rs_kernel", "block_fwd"), ("block_fwd_hw_kernel", "block_fwd"), ("block_bwd_attn", "block_bwd_attn"),
+short = [("block_fwd_rs_kernel", "block_fwd"), ("block_bwd_attn", "block_bwd_attn"),
          ("block_bwd_ln1mlp", "block_bwd_ln1mlp"), ("block_bwd_ln1", "block_bwd_ln1"),
          ("block_bwd_mlp", "block_bwd_mlp"), ("tokenize_bwd", "tokenize_bwd"), ("tokenize_fwd", "tokenize_fwd"),
          ("head_bwd", "head_bwd"), ("reduce_segs", "reduce_slabs"), ("adamw_kernel", "adamw"), ("head_fwd", "head_fwd"),
@@ -49,7 +49,7 @@ with open(os.path.join(DST, f"{tag}_pmc_summary.txt"), "w") as f:
         f.write(open(os.path.join(SRC, n)).read())
 for n, dst in (("dp_overlap.txt", f"{tag}_dp_overlap.txt"), ("parity_measured.jsonl", f"{tag}_parity_measured.jsonl"),
                ("gpu_tests.txt", f"{tag}_gpu_tests.txt"), ("peak_microbench.json", f"{tag}_peak_microbench.json"),
-               ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl")):
+               ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl"), ("gate_microbench.jsonl", f"{tag}_gate_microbench.jsonl")):
     if os.path.exists(os.path.join(SRC, n)):
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, dst))
 print(json.dumps(kern, indent=1))
