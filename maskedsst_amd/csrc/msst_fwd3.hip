@@ -48,6 +48,9 @@
                        // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
                        // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
 #endif
+#ifndef MSST_F3_FWBASE
+#define MSST_F3_FWBASE 0   // 1: out-projection weight requests as scalar base + immediate offset (measured round 5: 287 vs 278 us -- SLOWER: the five scalar instructions per request sat in the shadow of the previous request's issue, and 24 back-to-back requests are not faster)
+#endif
 #ifndef MSST_F3_YSC1
 #define MSST_F3_YSC1 0   // 1: the block output rows leave with sc1 (write-through, the line is dropped from the XCD's L2): leaves the L2 to the x rows the residual add re-reads
 #endif
@@ -562,10 +565,29 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // whole L2 latency (6 MFMAs of cover per k-step): 6.6 k cycles for 48 MFMAs.
     frag fw[8][3];
     auto request_fw = [&](int rd) {
+#if MSST_F3_FWBASE
+        // fragment (row tile 3 mh + i, k-step 8 rd + s8) of the packed [96][inner] matrix starts at byte 1024 ((3 mh + i) (inner / 32) + 8 rd + s8):
+        // six scalar bases per call (i x the two halves of s8) + the 12-bit offset field, instead of five scalar instructions
+        // per fragment (round 5: 24 fragments x 2 calls per tile were ~240 scalar instructions per R wave and tile, in q1 / q3 --
+        // the intervals in which the A waves wait for the R waves)
+        F3_LANE();
+        const int l16_ = l3 * 16, m_ = sopaque3(mh), kf = inner >> 5;
+        int base[3][2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            base[i][0] = ((3 * m_ + i) * kf + 8 * rd) * 1024;
+            base[i][1] = base[i][0] + 4096;
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fw[s8][i] = ld_wb3(wout, l16_ + (s8 & 3) * 1024, base[i][s8 >> 2]);
+#else
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
             for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque3(mh) + i) * 16, (8 * rd + s8) * 32);
+#endif
     };
     auto outproj = [&](int rd) {
         F3_LANE();
