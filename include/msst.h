@@ -129,6 +129,21 @@ int msst_block_fwd(const MsstBlockWeights* w /*host*/, const float* x, float* y,
                    int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed,
                    int layer, void* xn_out, float* lse_out, int* saved /*host*/, void* stream);
 
+/* The same forward for a RUN of blocks of ONE stack (same mode) as ONE launch (round 5): the blocks of a stack never mix the rows
+ * of different 64-row tiles (vit_spatial_spectral.py:410-431: the regroupings sit between the stacks), so a workgroup takes a tile
+ * through block after block -- block j reads what block j - 1 wrote, two blocks of one tile at least three pipeline steps apart --
+ * and the prologue + pipeline fill / drain of all launches but one go away (26 us each).  Bit-identical to nblk calls of
+ * msst_block_fwd with layer = layer0 .. layer0 + nblk - 1: block 0 reads x0, block j > 0 reads y[j - 1].
+ * w, y, x1, xn_out, lse_out: HOST arrays of nblk pointers (x1 / xn_out / lse_out may be NULL as a whole: nothing saved).
+ * Every per-block operand (each member of w[j], y[j], x1[j], xn_out[j], lse_out[j]) must lie a constant byte stride (|stride| < 2 GiB,
+ * one stride per operand) from block to block -- the kernel addresses block j as block 0 + j x stride instead of fetching pointers.
+ * The role-split bf16 forward only (8 heads; of the prec flags only MSST_X1_BF16), at most 16 blocks, and at most 1024 (tile, block)
+ * steps per workgroup: MSST_ERR_UNSUPPORTED otherwise (nothing launched) -- call msst_block_fwd per block then. */
+int msst_block_fwd_stack(const MsstBlockWeights* const* w /*host*/, int nblk, const float* x0, float* const* y /*host*/,
+                         float* const* x1 /*host*/, void* const* xn_out /*host*/, float* const* lse_out /*host*/, int mode,
+                         int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed, int layer0,
+                         int* saved /*host, optional*/, void* stream);
+
 /* a12-a14: gather of masked tokens, BlockwiseToPixels (vit_simmim_original.py:9-40,314-330),
  * target gather from the raw cube (:335) and mean-L1 / K (:338).
  * idx [B][K] int32; w_pix [S or 1][P][96], b_pix [S or 1][P]; per_block = to_pixels_per_spectral_block.

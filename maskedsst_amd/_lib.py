@@ -54,6 +54,8 @@ _SIGS = {
     "msst_block_lse_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_uint32, c_int, _P, _P, POINTER(c_int), _P]),
+    "msst_block_fwd_stack": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int,
+                                     POINTER(c_int), _P]),
     "msst_head_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, _P, _P, c_int, c_int, c_int, c_int,
                               c_int, _P]),
     "msst_head_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_int,

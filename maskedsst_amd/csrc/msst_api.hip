@@ -314,6 +314,83 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 
+int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float* x0, float* const* y, float* const* x1,
+                         void* const* xn_out, float* const* lse_out, int mode, int B, int S, int N, int heads, int prec, int max_grid,
+                         float dropout_p, uint32_t seed, int layer0, int* saved, void* stream) {
+    if (!w || !x0 || !y || nblk < 1) return fail(MSST_ERR_BADARG, "msst_block_fwd_stack");
+    if (nblk > MSST_MAX_STACK || N > 64 || S > 64) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (more than 16 blocks, or sequence length > 64)");
+    const int dbg = (prec >> 8) & 0xffff;
+    prec &= 0xff;
+    // the role-split bf16 forward only: 8 heads, no kernel selection flags (MSST_X1_BF16 is the one flag it takes)
+    if (prec != MSST_PREC_BF16 || heads != 8 || (dbg & ~1024)) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (bf16, 8 heads, no MSST_KERNEL_* flags)");
+    StackArgs sa;
+    BlockArgs& a = sa.base;
+    memset(&a.w, 0, sizeof(a.w));
+    a.x = x0; a.y = nullptr; a.x1 = nullptr; a.xn_out = nullptr; a.lse_out = nullptr;
+    a.tm = make_tilemap(mode, B, S, N);
+    a.ntiles = ntiles_of(a.tm);
+    a.max_grid = max_grid > 0 ? max_grid : a.ntiles;
+    a.H = heads;
+    a.scale = 0.125f;
+    a.dbg = 0;
+    a.stamps = nullptr;
+    a.x1_bf16 = (dbg & 1024) ? 1 : 0;
+    a.drop = make_drop(dropout_p, seed, layer0);
+    sa.nblk = nblk;
+    // the kernel addresses block j's operands as block 0's + j x a byte stride: every array of the call must be affine in the block
+    // index (maskedsst_amd lays its weight copies, parameters and activations out that way); anything else is refused
+    auto blk_of = [&](int j, const float* xin) {
+        StackBlk sb;
+        sb.wqkv = w[j]->wqkv; sb.wout = w[j]->wout; sb.w1 = w[j]->w1; sb.w2 = w[j]->w2;
+        sb.ln1_g = w[j]->ln1_g; sb.ln1_b = w[j]->ln1_b; sb.bo = w[j]->bo; sb.ln2_g = w[j]->ln2_g; sb.ln2_b = w[j]->ln2_b; sb.b1 = w[j]->b1; sb.b2 = w[j]->b2;
+        sb.x = xin; sb.y = y[j]; sb.x1 = x1 ? x1[j] : nullptr; sb.xn_out = xn_out ? xn_out[j] : nullptr; sb.lse_out = lse_out ? lse_out[j] : nullptr;
+        sb.layer = layer0 + j; sb.pad_ = 0;
+        return sb;
+    };
+    for (int j = 0; j < nblk; ++j)
+        if (!bw_ok(w[j]) || !y[j] || y[j] == (j ? y[j - 1] : x0))
+            return fail(MSST_ERR_BADARG, "msst_block_fwd_stack (null argument, or MsstBlockWeights of another header revision)");
+    sa.b0 = blk_of(0, x0);
+    memset(&sa.st, 0, sizeof(sa.st));
+    bool affine = true;
+    if (nblk > 1) {
+        const StackBlk b1 = blk_of(1, y[0]);
+        auto dist = [&](const void* p1, const void* p0, int& out) {
+            const long d = (const char*)p1 - (const char*)p0;
+            if (d > 0x7fffffffL || d < -0x7fffffffL) affine = false;
+            out = (int)d;
+        };
+        dist(b1.wqkv, sa.b0.wqkv, sa.st.wqkv); dist(b1.wout, sa.b0.wout, sa.st.wout); dist(b1.w1, sa.b0.w1, sa.st.w1); dist(b1.w2, sa.b0.w2, sa.st.w2);
+        dist(b1.ln1_g, sa.b0.ln1_g, sa.st.ln1_g); dist(b1.ln1_b, sa.b0.ln1_b, sa.st.ln1_b); dist(b1.bo, sa.b0.bo, sa.st.bo);
+        dist(b1.ln2_g, sa.b0.ln2_g, sa.st.ln2_g); dist(b1.ln2_b, sa.b0.ln2_b, sa.st.ln2_b); dist(b1.b1, sa.b0.b1, sa.st.b1); dist(b1.b2, sa.b0.b2, sa.st.b2);
+        dist(b1.y, sa.b0.y, sa.st.y); dist(b1.x1, sa.b0.x1, sa.st.x1); dist(b1.xn_out, sa.b0.xn_out, sa.st.xn_out); dist(b1.lse_out, sa.b0.lse_out, sa.st.lse_out);
+        // block j > 0 reads what block j - 1 wrote: x_j = y_(j-1) = y_0 + (j - 1) stride_y -- affine from block 1 on; block 0 reads x0.  The
+        // kernel takes x_j = x_base + j stride_y with x_base = y_0 - stride_y for j >= 1 and x0 for j = 0: keep both
+        sa.st.x = sa.st.y;
+        const float* xin = y[0];
+        for (int j = 1; j < nblk && affine; ++j) {
+            const StackBlk bj = blk_of(j, xin);
+            auto same = [&](const void* pj, const void* p0, int stride) { return !p0 ? !pj : (const char*)pj == (const char*)p0 + (long)j * stride; };
+            affine = same(bj.wqkv, sa.b0.wqkv, sa.st.wqkv) && same(bj.wout, sa.b0.wout, sa.st.wout) && same(bj.w1, sa.b0.w1, sa.st.w1) &&
+                     same(bj.w2, sa.b0.w2, sa.st.w2) && same(bj.ln1_g, sa.b0.ln1_g, sa.st.ln1_g) && same(bj.ln1_b, sa.b0.ln1_b, sa.st.ln1_b) &&
+                     same(bj.bo, sa.b0.bo, sa.st.bo) && same(bj.ln2_g, sa.b0.ln2_g, sa.st.ln2_g) && same(bj.ln2_b, sa.b0.ln2_b, sa.st.ln2_b) &&
+                     same(bj.b1, sa.b0.b1, sa.st.b1) && same(bj.b2, sa.b0.b2, sa.st.b2) && same(bj.y, sa.b0.y, sa.st.y) &&
+                     same(bj.x1, sa.b0.x1, sa.st.x1) && same(bj.xn_out, sa.b0.xn_out, sa.st.xn_out) && same(bj.lse_out, sa.b0.lse_out, sa.st.lse_out);
+            xin = y[j];
+        }
+    }
+    if (!affine) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (per-block operands not a constant stride apart)");
+    sa.x_rest = nblk > 1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(y[0]) - (long)sa.st.y) : x0;   // x of block j >= 1 = x_rest + j stride_y
+    if (saved) *saved = (xn_out ? MSST_SAVED_XN : 0) | (lse_out ? MSST_SAVED_LSE : 0);
+    if (a.ntiles < 1) return 0;
+    int ncu = 256, dev = 0;
+    hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 256;
+    int grid = a.max_grid < a.ntiles ? a.max_grid : a.ntiles;
+    if (grid > ncu) grid = ncu;
+    return fail(launch_block_fwd_rs_stack(sa, grid, (hipStream_t)stream), "msst_block_fwd_stack");
+}
+
 int msst_head_fwd(const float* y, const float* img, const int32_t* idx, const float* w_pix,
                   const float* b_pix, int per_block, float* dpred, float* pred, float* partial,
                   float* loss, int B, int S, int N, int P, int K, void* stream) {

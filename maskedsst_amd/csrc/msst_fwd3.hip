@@ -48,6 +48,9 @@
                        // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
                        // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
 #endif
+#ifndef MSST_F3_GROUP
+#define MSST_F3_GROUP 10   // stack walk: a workgroup's tiles are cut into nmine / MSST_F3_GROUP groups; measured 3: +1.8 %, 6: -1.4 %, 10: -2.5 %, 100: -1.7 % (bench brackets, against per-block launches)
+#endif
 #ifndef MSST_F3_FWBASE
 #define MSST_F3_FWBASE 0   // 1: out-projection weight requests as scalar base + immediate offset (measured round 5: 287 vs 278 us -- SLOWER: the five scalar instructions per request sat in the shadow of the previous request's issue, and 24 back-to-back requests are not faster)
 #endif
@@ -96,8 +99,20 @@ struct Fwd3Smem {
     unsigned long long vm[64];             // key-validity mask of a query row: bit k set <=> key row k belongs to the query's sequence (tile invariant)
     unsigned long long km[MSST_F3_KM ? 2 : 1][MSST_F3_KM ? 8 : 1][64];   // (MSST_F3_KM) keep mask of the attention-probability dropout (site 1): [walk-step parity][head][query row], bit = key
     int seqb[4][64];                       // token of position 0 of every sequence slot, tiles of walk steps k - 1 .. k + 1 (by k & 3)
-    float lnp[640];                        // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1
+    float lnp[2][640];                     // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1 of the block of a step; [1]: STACK only (the block a step pipeline
+                                           // runs into while the stages behind it still work for the block before)
     char wmlp[24 * 1024];                  // [w1: 12 frags | w2: 12 frags]
+    const char* blktab[MSST_MAX_STACK][16];   // (STACK) every per-block operand of the run, in StackBlk's member order: block 0's + block x its stride
+    unsigned steptab[1024];                // (STACK) walk step -> local tile index | block << 16 | lnp slot << 24 | idle << 31
+};
+constexpr int F3_MAX_STEPS = 1024;
+constexpr int BT_WQKV = 0, BT_W1 = 2, BT_LN1G = 4, BT_X = 11;   // blktab columns: wqkv wout | w1 w2 | ln1_g ln1_b bo ln2_g ln2_b b1 b2 | x y x1 xn_out lse_out
+
+// what a walk step works on (STACK: the step's block of the run; else the launch's one block)
+struct StepBlk {
+    const elem* wqkv; const elem* wout;
+    const float* x; float* y; float* x1; elem* xn_out; float* lse_out;
+    int layer;
 };
 
 __device__ __forceinline__ int sopaque3(int v) {
@@ -160,8 +175,19 @@ __device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* w
 
 }  // namespace
 
-template <bool DROP>
-__global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
+// STACK: ONE launch runs a RUN of blocks of one stack (same mode) -- the blocks of a stack never mix tiles, so a workgroup can take
+// a tile through block after block.  The walk is over (tile, block) steps instead of tiles: the tiles of a workgroup are cut into
+// groups of MSST_F3_GROUP or more (one group when it has fewer; a lone group of 1 or 2 is padded with idle steps to 3); a group goes
+// through block 0, then block 1, ... so that two blocks of one tile are at least three steps apart -- the distance at which the rows
+// a step's MLP stores (q3 of the step after it) have left the memory queue of their waves before LN1 of the next block requests
+// them (q2 of the step after that).  Everything else is the per-block kernel: same arithmetic, same stores, bit-identical results;
+// what goes away is the prologue + pipeline fill / drain of eleven of twelve launches.  Measured (tools/fwd_ab.py, LABNOTES round 5):
+// 6.9 us per block saved, 4 % per step lost (block switches every group: MLP weights and small vectors reloaded, the weight ring
+// running into lines that left L2; 150 more scalar / LDS instructions per step in the R waves) -- ahead below ~14 tiles per
+// workgroup (batch 64, 5 / 6 tiles: -5.5 %; Houston shape: -7.3 %), behind above (batch 256 at the EnMAP shape, 20 / 22: +1.3 %): the host picks.
+template <bool DROP, bool STACK>
+__global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::conditional<STACK, StackArgs, BlockArgs>::type args) {
+    const BlockArgs& a = [&]() -> const BlockArgs& { if constexpr (STACK) return args.base; else return args; }();
     typedef Fwd3Smem SM;
     constexpr int LDX = SM::LDX, LDH = SM::LDH, LDO = SM::LDO;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -169,26 +195,130 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 
     const int tid = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(tid >> 6), l = tid & 63, g = l >> 4, c = l & 15;
     const int H = a.H, inner = H * 64;
-    const elem* wqkv = reinterpret_cast<const elem*>(a.w.wqkv);
-    const elem* wout = reinterpret_cast<const elem*>(a.w.wout);
     const TileMap tm = a.tm;
     const int L = tm.L;
     const int G = (int)gridDim.x;
     const int nmine = ((int)blockIdx.x < a.ntiles) ? (a.ntiles - 1 - (int)blockIdx.x) / G + 1 : 0;
-    auto tile_at = [&](int k) { return (int)blockIdx.x + k * G; };
+    // ---- the walk: steps 0 .. nsteps - 1 ----
+    int nsteps = nmine;
+    if constexpr (STACK) {
+        // groups of 3 .. 5 tiles (a lone group of 1 or 2 is padded with idle steps to 3); group j walks its tiles block by block
+        const int nblk = args.nblk;
+        const int ng = max(1, nmine / MSST_F3_GROUP), gbase = nmine / ng, gextra = nmine - gbase * ng;   // group j holds gbase + (j < gextra) tiles
+        const int p1 = max(gbase + 1, 3), p0 = max(gbase, 3);                                // ... and takes nblk * p steps
+        nsteps = nmine ? nblk * (gextra * p1 + (ng - gextra) * p0) : 0;
+        for (int s_ = tid; s_ < nsteps; s_ += 512) {
+            const int head = gextra * nblk * p1;
+            int j, r, pp, sz, before;
+            if (s_ < head) { j = s_ / (nblk * p1); r = s_ - j * nblk * p1; pp = p1; sz = gbase + 1; before = j * (gbase + 1); }
+            else { j = gextra + (s_ - head) / (nblk * p0); r = s_ - head - (j - gextra) * nblk * p0; pp = p0; sz = gbase; before = gextra * (gbase + 1) + (j - gextra) * gbase; }
+            const int blk = r / pp, pos = r - blk * pp;
+            const unsigned idle = pos >= sz ? 1u : 0u;
+            sm.steptab[s_] = (unsigned)(before + min(pos, sz - 1)) | ((unsigned)blk << 16) | ((unsigned)((j * nblk + blk) & 1) << 24) | (idle << 31);
+        }
+    }
+    if constexpr (STACK) {
+        // per-block operands -> LDS, straight from the kernel-argument segment (StackBlk is sixteen pointers, StackStride sixteen strides, same order)
+        static_assert(offsetof(StackBlk, lse_out) == 15 * 8 && offsetof(StackStride, lse_out) == 15 * 4, "blktab follows StackBlk's member order");
+        for (int e = tid; e < args.nblk * 16; e += 512) {
+            const int j = e >> 4, f = e & 15;
+            auto kp = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+            const char* p0 = *(const char* const __attribute__((address_space(4)))*)(kp + offsetof(StackArgs, b0) + f * 8);
+            const int stride = *(const int __attribute__((address_space(4)))*)(kp + offsetof(StackArgs, st) + f * 4);
+            const char* pj = p0 ? p0 + (long)j * stride : nullptr;
+            if (f == BT_X && j) pj = reinterpret_cast<const char*>(args.x_rest) + (long)j * args.st.y;
+            sm.blktab[j][f] = pj;
+        }
+    }
+    // The step words of the steps a loop iteration touches (k - 2 .. k + 2) are carried in scalars from iteration to iteration (one
+    // LDS read per step, a step ahead): a lookup per use -- table read, readfirstlane, then a pointer fetch that depends on it, in
+    // every stage of the R waves -- cost the first version of the stack walk more than the launches it saved (275 vs 268 us per block).
+    constexpr unsigned F3_IDLE = 0x80000000u;
+    auto load_word = [&](int k) -> unsigned {
+        if constexpr (STACK) return (k >= 0 && k < nsteps) ? (unsigned)__builtin_amdgcn_readfirstlane((int)sm.steptab[k]) : F3_IDLE;
+        else return (k >= 0 && k < nmine) ? (unsigned)k : F3_IDLE;
+    };
+    int kc = 0;                                   // the step the cached words are centred on: the walk loops count in it, so that k - kc below folds to a constant
+    unsigned swm2 = F3_IDLE, swm1 = F3_IDLE, sw0 = F3_IDLE, swp1 = F3_IDLE, swp2 = F3_IDLE;
+    auto step_word = [&](int k) -> unsigned {
+        if constexpr (!STACK) return load_word(k);
+        else { const int d = k - kc; return d == 0 ? sw0 : d == 1 ? swp1 : d == -1 ? swm1 : d == 2 ? swp2 : d == -2 ? swm2 : load_word(k); }
+    };
+    auto words_init = [&]() { kc = 0; swm2 = F3_IDLE; swm1 = F3_IDLE; sw0 = load_word(0); swp1 = load_word(1); swp2 = load_word(2); };
+    auto words_advance = [&]() { swm2 = swm1; swm1 = sw0; sw0 = swp1; swp1 = swp2; swp2 = load_word(kc + 3); };   // (last statement of an iteration: kc is still the old step)
+    // tile of walk step k; < 0: no tile (outside the walk, or an idle step)
+    auto tile_at = [&](int k) -> int {
+        const unsigned w_ = step_word(k);
+        return (w_ >> 31) ? -1 : (int)blockIdx.x + (int)(w_ & 0xffffu) * G;
+    };
+    auto blk_at = [&](int k) -> int { if constexpr (STACK) return (int)((step_word(k) >> 16) & 0xffu); else return 0; };
+    auto slot_at = [&](int k) -> int { if constexpr (STACK) return (int)((step_word(k) >> 24) & 1u); else return 0; };
+    auto in_walk = [&](int k) -> bool { return k >= 0 && k < nsteps; };
+    // does the walk move on to another block between steps k0 and k1 = k0 + 1 (another group's block 0 included)?
+    auto epoch_differs = [&](int k1, int k0) -> bool {
+        if constexpr (STACK) return in_walk(k1) && in_walk(k0) && ((step_word(k1) ^ step_word(k0)) & 0x01ff0000u) != 0u;
+        else return false;
+    };
+    // per-block pointers: block 0's + block index x a byte stride (the host checked that every array of the call is affine in the
+    // block index: msst_block_fwd_stack) -- scalar arithmetic, no table in memory
+    auto at_blk = [&](const void* p0, int stride, int blk) -> const char* { return reinterpret_cast<const char*>(p0) + (long)blk * (long)stride; };
+    auto step_blk = [&](int k) -> StepBlk {
+        StepBlk q;
+        if constexpr (STACK) {
+            const int j = blk_at(k);
+            const StackBlk& b0 = args.b0;
+            const StackStride& st = args.st;
+            q.wqkv = reinterpret_cast<const elem*>(at_blk(b0.wqkv, st.wqkv, j)); q.wout = reinterpret_cast<const elem*>(at_blk(b0.wout, st.wout, j));
+            // (the row pointers are used by the R waves only, as the base of per-lane addresses: from the table in LDS -- the walk of
+            // the R waves spilled 77 scalar registers to VGPR lanes with all of the run's operands held in scalars, 247 v_readlane a step)
+            q.x = reinterpret_cast<const float*>(sm.blktab[j][BT_X]);   // block j > 0 reads block j - 1's y
+            q.y = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[j][BT_X + 1]));
+            q.x1 = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[j][BT_X + 2]));
+            q.xn_out = reinterpret_cast<elem*>(const_cast<char*>(sm.blktab[j][BT_X + 3]));
+            q.lse_out = b0.lse_out ? reinterpret_cast<float*>(const_cast<char*>(at_blk(b0.lse_out, st.lse_out, j))) : nullptr;
+            q.layer = b0.layer + j;
+        } else {
+            q.wqkv = reinterpret_cast<const elem*>(a.w.wqkv); q.wout = reinterpret_cast<const elem*>(a.w.wout);
+            q.x = a.x; q.y = a.y; q.x1 = a.x1; q.xn_out = reinterpret_cast<elem*>(a.xn_out); q.lse_out = a.lse_out; q.layer = a.drop.layer;
+        }
+        return q;
+    };
+    auto drop_at = [&](int k) -> Drop { Drop d = a.drop; if constexpr (STACK) d.layer = args.b0.layer + blk_at(k); return d; };
+    auto lnp_at = [&](int k) -> const float* { return sm.lnp[slot_at(k)]; };
+    // small parameter vectors of block `blk` -> lnp[slot] (96 threads, t96 = 0 .. 95)
+    struct LnpRegs { float v[7]; };
+    auto fetch_lnp = [&](int blk, int t96) -> LnpRegs {
+        const float *g1, *b1_, *bo, *g2, *b2_, *bb2, *bb1;
+        if constexpr (STACK) {
+            auto fp_ = [&](int f) { return reinterpret_cast<const float*>(sm.blktab[blk][f]); };
+            g1 = fp_(BT_LN1G); b1_ = fp_(BT_LN1G + 1); bo = fp_(BT_LN1G + 2); g2 = fp_(BT_LN1G + 3); b2_ = fp_(BT_LN1G + 4); bb1 = fp_(BT_LN1G + 5); bb2 = fp_(BT_LN1G + 6);
+        }
+        else { g1 = a.w.ln1_g; b1_ = a.w.ln1_b; bo = a.w.bo; g2 = a.w.ln2_g; b2_ = a.w.ln2_b; bb2 = a.w.b2; bb1 = a.w.b1; }
+        LnpRegs r;
+        r.v[0] = g1[t96]; r.v[1] = b1_[t96]; r.v[2] = bo[t96]; r.v[3] = g2[t96]; r.v[4] = b2_[t96]; r.v[5] = bb2[t96];
+        r.v[6] = bb1[t96 < 64 ? t96 : 0];
+        return r;
+    };
+    auto commit_lnp = [&](int slot, int t96, const LnpRegs& r) {
+        float* lnp = sm.lnp[slot];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) lnp[96 * i + t96] = r.v[i];
+        if (t96 < 64) lnp[576 + t96] = r.v[6];
+    };
+    auto load_lnp = [&](int slot, int blk, int t96) { commit_lnp(slot, t96, fetch_lnp(blk, t96)); };
+    auto mlp_w = [&](int blk, int which) -> const char* {
+        if constexpr (STACK) return sm.blktab[blk][BT_W1 + which];
+        else return reinterpret_cast<const char*>(which ? a.w.w2 : a.w.w1);
+    };
 
     // ---- common prologue: small parameter vectors, MLP weights, token tables ----
-    float* lnp = sm.lnp;
-    if (tid < 96) {
-        lnp[tid] = a.w.ln1_g[tid]; lnp[96 + tid] = a.w.ln1_b[tid]; lnp[192 + tid] = a.w.bo[tid];
-        lnp[288 + tid] = a.w.ln2_g[tid]; lnp[384 + tid] = a.w.ln2_b[tid]; lnp[480 + tid] = a.w.b2[tid];
-        if (tid < 64) lnp[576 + tid] = a.w.b1[tid];
-    }
+    if (STACK) __syncthreads();   // the step table
+    words_init();
+    if (tid < 96) load_lnp(slot_at(0), blk_at(0), tid);
 #pragma unroll
     for (int i3 = 0; i3 < 3; ++i3) {
         const int f = wv * 3 + i3;
-        dma_frag(f < 12 ? reinterpret_cast<const char*>(a.w.w1) + f * 1024 : reinterpret_cast<const char*>(a.w.w2) + (f - 12) * 1024,
-                 sm.wmlp + f * 1024);
+        dma_frag(f < 12 ? mlp_w(blk_at(0), 0) + f * 1024 : mlp_w(blk_at(0), 1) + (f - 12) * 1024, sm.wmlp + f * 1024);
     }
     wait_vm0();
     if (tid < 64) {
@@ -200,7 +330,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         const int tile_ = tile_at(k);
         const int q = tile_ * tm.TS + t64;
         int base = -1;
-        if (k >= 0 && k < nmine && t64 < tm.TS && q < tm.nseq) {
+        if (tile_ >= 0 && t64 < tm.TS && q < tm.nseq) {
             if (tm.mode == 0) base = q * tm.N;
             else { const int b = tm.nshift >= 0 ? (q >> tm.nshift) : q / tm.N; base = b * tm.T + (q - b * tm.N); }
         }
@@ -249,19 +379,29 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         // (pair p of a head always lives in slot p % NR: for pi >= 18 - NR the freed slots pi % NR run through 0 .. NR - 1 exactly once)
         auto next_pair = [](int pi) { return pi + NR < 18 ? pi + NR : pi % NR; };
         const int HB = H * 12288, l16 = l * 16;
-        const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc(a.lse_out, 0, a.lse_out ? (int)min((long)a.ntiles * H * 256, 0x7fffffffL) : 0, 0x00020000);
+        {
+            const elem* wq0 = step_blk(0).wqkv;
 #pragma unroll
-        for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wqkv, H, wv, voff, wv * 12288, HB, l16);
+            for (int pi = 0; pi < NR; ++pi) load_pair3(pi, ring[pi], wq0, H, wv, voff, wv * 12288, HB, l16);
+        }
 
         __syncthreads();   // (P1) LN1 of the first tile is in XN[0]
-        for (int k = 0; k < nmine; ++k) {
-            const int tile = tile_at(k);
+        for (kc = 0; kc < nsteps; ++kc) {
+            const int k = kc;
+            const int tile = tile_at(k);   // (STACK: < 0 for an idle step -- its rows are all padding, nothing of it is stored)
+            const StepBlk sb = step_blk(k);
+            const elem* wqkv = sb.wqkv;
+            const elem* wqkv_next = (STACK && k + 1 < nsteps) ? step_blk(k + 1).wqkv : sb.wqkv;   // where the weight ring wraps to at the end of round 1
+            const Drop drop_k = drop_at(k);
+            // (the range check of a buffer store covers the lane offset only: an idle step -- or no buffer -- gets zero records)
+            const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc(sb.lse_out, 0, (sb.lse_out && tile >= 0) ? (int)min((long)a.ntiles * H * 256, 0x7fffffffL) : 0, 0x00020000);
 #ifdef MSST_STAMPS
-            const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nmine / 2;
+            const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nsteps / 2;
 #endif
             F3_STAMP(0);
 #pragma unroll
             for (int rd = 0; rd < 2; ++rd) {
+                const elem* wq_wrap = rd == 1 ? wqkv_next : wqkv;   // the pairs past this head's last belong to the wave's next head
                 const int h = wv + 4 * rd;                  // this round's head
                 const int hn = wv + 4 * (1 - rd);           // the head whose first pairs follow in the weight stream
                 const int hb_c = sopaque3(h * 12288), hb_n = sopaque3(hn * 12288);   // (opaque per round: folded into 36 per-pair constants they would be hoisted out of the walk and spilled)
@@ -288,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                     cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
+                                load_pair3(next_pair(pi), ring[pi % NR], pi + NR < 18 ? wqkv : wq_wrap, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
 #pragma unroll
@@ -309,7 +449,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                     ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
-                                load_pair3(next_pair(pi), ring[pi % NR], wqkv, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
+                                load_pair3(next_pair(pi), ring[pi % NR], pi + NR < 18 ? wqkv : wq_wrap, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
                             vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
@@ -416,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const float st = colgroup_sum(sum[u]);
-                            inv[u] = (DROP ? a.drop.scale : 1.f) * __builtin_amdgcn_rcpf(st);   // the dropout scale rides on the normalisation
+                            inv[u] = (DROP ? drop_k.scale : 1.f) * __builtin_amdgcn_rcpf(st);   // the dropout scale rides on the normalisation
                             // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head).  One
                             // buffer store, no branch: (tile, head) rides in the scalar offset, the query row in the lane offset; a query's
                             // value is replicated over the four lane groups, which all write it (an out-of-range offset -- no buffer given:
@@ -441,7 +581,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                                     for (int r = 0; r < 4; ++r)
                                         s[u][t][r] = __int_as_float(__float_as_int(s[u][t][r]) & __builtin_amdgcn_sbfe(t < 2 ? klo : khi, 16 * (t & 1) + sh0 + r, 1));
                                 } else if (DROP) {
-                                    s[u][t] = drop4_noscale(a.drop, 1, (unsigned)(((tile * H + h) * 64 + (2 * jp + u) * 16 + cq) * 16 + t * 4 + (sh0 >> 2)), s[u][t]);
+                                    s[u][t] = drop4_noscale(drop_k, 1, (unsigned)(((tile * H + h) * 64 + (2 * jp + u) * 16 + cq) * 16 + t * 4 + (sh0 >> 2)), s[u][t]);
                                 }
                             }
                         }
@@ -483,7 +623,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     attn_pair(I1{}, std::true_type{}, std::integral_constant<int, 0xf>{}, std::integral_constant<int, 0xf>{});
                 }
             }
+            if constexpr (STACK) words_advance();
         }
+        // (the A waves' walk ends here)
         // the R waves finish the last tile: four more intervals
 #pragma unroll
         for (int i = 0; i < 4; ++i) lds_barrier();
@@ -503,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         int rt = (int)threadIdx.x - 256;
         asm volatile("" : "+v"(rt));
         const long tok = tok_of(k, rt >> 2);
-        const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 4 * (rt & 3);
+        const float* xrow = step_blk(k).x + (tok >= 0 ? tok : 0) * 96 + 4 * (rt & 3);
 #pragma unroll
         for (int i = 0; i < 6; ++i) xv[i] = *reinterpret_cast<const f32x4*>(xrow + 16 * i);
     };
@@ -512,6 +654,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         asm volatile("" : "+v"(rt));
         const int lr = rt >> 2, part = rt & 3;
         const long tok = tok_of(k, lr);
+        const float* lnp = lnp_at(k);
+        elem* const xn_out = step_blk(k).xn_out;
         float v[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
@@ -535,7 +679,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
             for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[f0 + e] + lnp[96 + f0 + e];
             const s16x4 nb = f2bf4(n4);
             *reinterpret_cast<s16x4*>(&sm.xn[k & 1][lr][f0]) = nb;
-            if (a.xn_out && tok >= 0) *reinterpret_cast<s16x4*>(reinterpret_cast<elem*>(a.xn_out) + tok * 96 + f0) = nb;
+            if (xn_out && tok >= 0) *reinterpret_cast<s16x4*>(xn_out + tok * 96 + f0) = nb;
         }
     };
 
@@ -554,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
-            const float* xrow = a.x + (tok >= 0 ? tok : 0) * 96 + 48 * mh + 4 * g3;
+            const float* xrow = step_blk(k).x + (tok >= 0 ? tok : 0) * 96 + 48 * mh + 4 * g3;
 #pragma unroll
             for (int i = 0; i < 3; ++i) xr[jj][i] = *reinterpret_cast<const f32x4*>(xrow + 16 * i);
         }
@@ -564,7 +708,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // barrier wait hides the L2 round trip: requested inside the phase through a ring of four k-steps, every refill sat out a
     // whole L2 latency (6 MFMAs of cover per k-step): 6.6 k cycles for 48 MFMAs.
     frag fw[8][3];
-    auto request_fw = [&](int rd) {
+    auto request_fw = [&](int rd, int kstep) {
+        const elem* wout = step_blk(kstep).wout;
 #if MSST_F3_FWBASE
         // fragment (row tile 3 mh + i, k-step 8 rd + s8) of the packed [96][inner] matrix starts at byte 1024 ((3 mh + i) (inner / 32) + 8 rd + s8):
         // six scalar bases per call (i x the two halves of s8) + the 12-bit offset field, instead of five scalar instructions
@@ -607,6 +752,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // bias, dropout, residual -> x1 (registers + HBM); partial LN2 statistics of the 48 owned features -> ST
     auto epilogue1 = [&](int k) {
         F3_LANE();
+        const float* lnp = lnp_at(k);
+        const Drop drop_k = drop_at(k);
+        float* const x1p = step_blk(k).x1;
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
@@ -617,15 +765,15 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 f32x4 o4 = acc[jj][i];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o4[r] += lnp[192 + m0 + r];
-                if (DROP && tok >= 0) o4 = drop4(a.drop, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                if (DROP && tok >= 0) o4 = drop4(drop_k, 2, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                 o4 = o4 + xr[jj][i];
                 x1r[jj][i] = o4;
                 s1 += (o4[0] + o4[1]) + (o4[2] + o4[3]);
                 // saved for the MLP-half backward: fp32 here; the bf16 form (MSST_X1_BF16: a quarter of this kernel's writes less) leaves
                 // in ln2(), CENTRED on the row mean that is only known there
-                if (a.x1 && tok >= 0 && !a.x1_bf16) *reinterpret_cast<f32x4*>(a.x1 + tok * 96 + m0) = o4;
+                if (x1p && tok >= 0 && !a.x1_bf16) *reinterpret_cast<f32x4*>(x1p + tok * 96 + m0) = o4;
 #ifdef MSST_LAB
-                if (MSST_LAB_X1OLD && a.x1 && tok >= 0 && a.x1_bf16) *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(o4);   // (round 4's uncentred rows, for timing only)
+                if (MSST_LAB_X1OLD && x1p && tok >= 0 && a.x1_bf16) *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(x1p) + tok * 96 + m0) = f2bf4(o4);   // (round 4's uncentred rows, for timing only)
 #endif
             }
             const float mw = colgroup_sum(s1) * (1.f / 48.f);
@@ -640,8 +788,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         }
     };
     // LN2 of the owned rows (statistics combined with the other feature half) -> XN2
-    auto ln2 = [&]() {
+    auto ln2 = [&](int k) {
         F3_LANE();
+        const float* lnp = lnp_at(k);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const float2 other = sm.st[rw ^ 1][16 * jj + c3];
@@ -665,7 +814,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // (a trained residual stream with |mean| >> std would otherwise lose its LN2 statistics to the rounding).  The mean is known
     // since ln2() (q1, where the A waves wait for the R waves); the stores leave in q2, where the R waves have slack.
     auto store_x1_bf16 = [&](int k) {
-        if (!(a.x1 && a.x1_bf16)) return;
+        float* const x1p = step_blk(k).x1;
+        if (!(x1p && a.x1_bf16)) return;
 #ifdef MSST_LAB
         if (MSST_LAB_X1OLD) return;
 #endif
@@ -680,13 +830,15 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 f32x4 c4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) c4[r] = x1r[jj][i][r] - mean_r[jj];
-                *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(a.x1) + tok * 96 + m0) = f2bf4(c4);
+                *reinterpret_cast<s16x4*>(reinterpret_cast<unsigned short*>(x1p) + tok * 96 + m0) = f2bf4(c4);
             }
         }
     };
     // MLP GEMM 1 + GELU: rows 32 rh .., hidden units 32 mh .. + 31 -> HB
     auto mlp1 = [&](int k) {
         F3_LANE();
+        const float* lnp = lnp_at(k);
+        const Drop drop_k = drop_at(k);
         f32x4 hh[2][2];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) { hh[jj][0] = zero4(); hh[jj][1] = zero4(); }
@@ -713,7 +865,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                 const int n0 = (2 * mh + jn) * 16 + 4 * g3;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hh[jj][jn][r] = gelu_fast(hh[jj][jn][r] + lnp[576 + n0 + r]);
-                if (DROP && tok >= 0) hh[jj][jn] = drop4(a.drop, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jj][jn]);
+                if (DROP && tok >= 0) hh[jj][jn] = drop4(drop_k, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jj][jn]);
                 P::st_nat(&sm.hb[(2 * rh + jj) * 16][(2 * mh + jn) * 16], LDH, hh[jj][jn]);
             }
         }
@@ -721,6 +873,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // MLP GEMM 2 + bias, dropout, residual -> y
     auto mlp2 = [&](int k) {
         F3_LANE();
+        const float* lnp = lnp_at(k);
+        const Drop drop_k = drop_at(k);
+        float* const yp = step_blk(k).y;
         f32x4 yy[2][3];
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -751,10 +906,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
                     f32x4 o4;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o4[r] = yy[jj][jm][r] + lnp[480 + m0 + r];
-                    if (DROP) o4 = drop4(a.drop, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
+                    if (DROP) o4 = drop4(drop_k, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                     o4 = o4 + x1r[jj][jm];
-                    if (MSST_F3_YSC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(a.y + tok * 96 + m0), "v"(o4) : "memory");
-                    else *reinterpret_cast<f32x4*>(a.y + tok * 96 + m0) = o4;
+                    if (MSST_F3_YSC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(yp + tok * 96 + m0), "v"(o4) : "memory");
+                    else *reinterpret_cast<f32x4*>(yp + tok * 96 + m0) = o4;
                 }
             }
         }
@@ -769,19 +924,20 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     // keep masks of the attention-probability dropout of walk step k -> km[k & 1]: R lane rt hashes the 16 element groups of
     // (head, query row) = (2 part + rt / 128 ..., rt % 64): two rows per lane and tile, one per call (part = 0, 1)
     auto keep_masks = [&](int k, int part) {
-        if (!DROP || !MSST_F3_KM || k >= nmine) return;
+        if (!DROP || !MSST_F3_KM || k >= nsteps) return;
         int rt = (int)threadIdx.x - 256;
         asm volatile("" : "+v"(rt));
         const int hq = part * 256 + rt, hh = hq >> 6, q = hq & 63;   // head 0..7, query row 0..63
         const unsigned base = (unsigned)(((tile_at(k) * H + hh) * 64 + q) * 16);
         const unsigned t16 = a.drop.thr << 16;
+        const Drop drop_k = drop_at(k);
         unsigned w[2] = {0u, 0u};
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int gg = 0; gg < 4; ++gg) {
                 unsigned ha, hb;
-                drop_bits(a.drop, 1, base + (unsigned)(t * 4 + gg), ha, hb);
+                drop_bits(drop_k, 1, base + (unsigned)(t * 4 + gg), ha, hb);
                 const unsigned bits = (unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
                                       ((unsigned)(hb >= t16) << 3);
                 w[t >> 1] |= bits << (16 * (t & 1) + 4 * gg);
@@ -793,41 +949,67 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
     ln1(0);
     keep_masks(0, 0); keep_masks(0, 1);
     zero_acc();
-    request_fw(0);   // (a definition on every path: step 0 has no out-projection in q0)
+    request_fw(0, 0);   // (a definition on every path: step 0 has no out-projection in q0)
     __syncthreads();   // (P1)
     if (MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);   // the R waves are the later-dispatched half: they lose every VALU arbitration to the A wave of their SIMD otherwise
-    // walk steps 0 .. nmine: step k runs q0 / q1 for tile k - 1 (k >= 1), q2 for tile k (k < nmine) and tile k - 1, q3 for tiles k - 1 and k + 1
-    for (int k = 0; k <= nmine; ++k) {
-        const bool have_prev = k >= 1, have_cur = k < nmine;
+    // walk steps 0 .. nsteps: step k runs q0 / q1 for step k - 1 (k >= 1), q2 for step k (k < nsteps) and step k - 1, q3 for steps k - 1 and k + 1
+    bool lnp_switch = false;
+    LnpRegs lnp_regs = {};
+    for (kc = 0; kc <= nsteps; ++kc) {
+        const int k = kc;
+        const bool have_prev = k >= 1, have_cur = k < nsteps;
 #ifdef MSST_STAMPS
-        const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nmine / 2;
+        const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nsteps / 2;
 #endif
         F3_STAMP(0);
         // ---------------- q0 ----------------
         if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO02);
+        if constexpr (STACK) {
+            // the MLP of step k - 1 (q2 / q3 of this step) belongs to another block than the one before it: its 24 weight fragments
+            // replace the old ones now -- the MLP of step k - 2 finished in q3 of the step before -- and are waited for at the end of q0
+            if (k >= 2 && epoch_differs(k - 1, k - 2)) {
+                const int bk = blk_at(k - 1);
+#pragma unroll
+                for (int i6 = 0; i6 < 6; ++i6) {
+                    const int f = rw * 6 + i6;
+                    dma_frag_async(f < 12 ? mlp_w(bk, 0) + f * 1024 : mlp_w(bk, 1) + (f - 12) * 1024, sm.wmlp + f * 1024);
+                }
+            }
+            // the walk moves on to another block with step k + 1: its small vectors go to the other lnp buffer (first read by LN1 of
+            // step k + 1 at the end of q3; the buffer's last reader, the MLP of the block before this step's, finished a step ago)
+            // -- requested here, stored to LDS at the end of q0: the round trip runs under the out-projection
+            lnp_switch = k + 1 < nsteps && epoch_differs(k + 1, k);
+            if (lnp_switch && rt < 96) lnp_regs = fetch_lnp(blk_at(k + 1), rt);
+        }
         if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); }
         if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 0); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(2);
+        // STACK: every memory operation of this wave so far -- the y / x1 rows the steps before stored above all: LN1 of the same tile's
+        // NEXT block requests them in q2 of this step at the earliest -- and the MLP weight copy of this interval have completed
+        if constexpr (STACK) {
+            if (lnp_switch && rt < 96) commit_lnp(slot_at(k + 1), rt, lnp_regs);
+            wait_vm0();
+        }
         lds_barrier();
         F3_STAMP(3);
         // ---------------- q1 ----------------
         if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);
-        if (have_prev) ln2();
+        if (have_prev) ln2(k - 1);
         if (!MSST_F3_KMQ) keep_masks(k + 1, 0);
         if (rt < 64) fill_seq(k + 2, rt);   // (first read in q1 of the next step: LN1 request of step k + 2)
         if (have_cur) zero_acc();
-        request_fw(0);
+        request_fw(0, have_cur ? k : k - 1);
         F3_STAMP(4);
         lds_barrier();
         F3_STAMP(5);
         // ---------------- q2 ----------------
         if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO02);
-        if (MSST_F3_LN1Q == 2 && k + 1 < nmine) request_ln1(k + 1);
+        if (MSST_F3_LN1Q == 2 && k + 1 < nsteps) request_ln1(k + 1);
         if (have_cur) outproj(0);
         F3_STAMP(6);
         if (have_prev) { store_x1_bf16(k - 1); mlp1(k - 1); }
-        if (MSST_F3_LN1Q == 2 && k + 1 < nmine) ln1(k + 1);
-        if (MSST_F3_LN1Q == 3 && k + 1 < nmine) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
+        if (MSST_F3_LN1Q == 2 && k + 1 < nsteps) ln1(k + 1);
+        if (MSST_F3_LN1Q == 3 && k + 1 < nsteps) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
         if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 1); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(7);
         lds_barrier();
@@ -837,30 +1019,53 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(BlockArgs a) {
         if (have_prev) mlp2(k - 1);
         if (!MSST_F3_KMQ) keep_masks(k + 1, 1);
         F3_STAMP(9);
-        if (MSST_F3_LN1Q == 3 && k + 1 < nmine) ln1(k + 1);
-        request_fw(1);
+        if (MSST_F3_LN1Q == 3 && k + 1 < nsteps) ln1(k + 1);
+        request_fw(1, have_cur ? k : k - 1);
         F3_STAMP(10);
         lds_barrier();
         F3_STAMP(11);
+        if constexpr (STACK) words_advance();
     }
 }
 
-int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st) {
+static int fwd3_attrs() {
     static std::atomic<bool> attr_set{false};
+    if (attr_set) return 0;
+    const void* ks[4] = {reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, false>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, false>),
+                         reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, true>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, true>)};
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Fwd3Smem));
+        if (e != hipSuccess) return (int)e;
+    }
+    attr_set = true;
+    return 0;
+}
+
+// max tiles per workgroup x blocks a stack launch can walk (its step table lives in LDS)
+int block_fwd_stack_max_steps() { return F3_MAX_STEPS; }
+
+int launch_block_fwd_rs_stack(const StackArgs& sa, int grid, hipStream_t st) {
+    const BlockArgs& a = sa.base;
+    if (a.H != 8 || sa.nblk < 1 || sa.nblk > MSST_MAX_STACK || grid < 1) return MSST_ERR_UNSUPPORTED;
+    // steps of the busiest workgroup: its tiles in groups of >= 3 (a lone group of 1 or 2 is padded to 3)
+    const int nmine = (a.ntiles + grid - 1) / grid;
+    if (sa.nblk * (nmine < 3 ? 3 : nmine) > F3_MAX_STEPS) return MSST_ERR_UNSUPPORTED;
+    int rc = fwd3_attrs();
+    if (rc) return rc;
+    ProfScope ps(K_BLOCK_FWD, st);
+    if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, true>), dim3(grid), dim3(512), sizeof(Fwd3Smem), st, sa);
+    else hipLaunchKernelGGL((block_fwd_rs_kernel<false, true>), dim3(grid), dim3(512), sizeof(Fwd3Smem), st, sa);
+    return (int)hipGetLastError();
+}
+
+int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st) {
     const size_t smem = sizeof(Fwd3Smem);
     if (a.H != 8) return MSST_ERR_UNSUPPORTED;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_rs_kernel<false>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_fwd_rs_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    int rc = fwd3_attrs();
+    if (rc) return rc;
     ProfScope ps(K_BLOCK_FWD, st);
-    if (a.drop.thr) hipLaunchKernelGGL(block_fwd_rs_kernel<true>, dim3(grid), dim3(512), smem, st, a);
-    else hipLaunchKernelGGL(block_fwd_rs_kernel<false>, dim3(grid), dim3(512), smem, st, a);
+    if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, false>), dim3(grid), dim3(512), smem, st, a);
+    else hipLaunchKernelGGL((block_fwd_rs_kernel<false, false>), dim3(grid), dim3(512), smem, st, a);
     return (int)hipGetLastError();
 }
 

@@ -44,6 +44,26 @@ struct BlockArgs {
     Drop drop;
 };
 
+// A run of blocks of ONE stack (same mode) as one launch of the role-split forward (msst_fwd3.hip, STACK): per-block operands
+#define MSST_MAX_STACK 16
+struct StackBlk {
+    const void* wqkv; const void* wout; const void* w1; const void* w2;
+    const float* ln1_g; const float* ln1_b; const float* bo; const float* ln2_g; const float* ln2_b; const float* b1; const float* b2;
+    const float* x; float* y; float* x1; void* xn_out; float* lse_out;
+    int layer, pad_;
+};
+struct StackStride {   // byte distance of every per-block operand from one block of the run to the next (the caller's arrays are affine in the block index)
+    int wqkv, wout, w1, w2, ln1_g, ln1_b, bo, ln2_g, ln2_b, b1, b2, x, y, x1, xn_out, lse_out;
+};
+struct StackArgs {
+    BlockArgs base;   // what does not depend on the block: tile map, heads, scale, dropout stream (its `layer` is per block below), x1_bf16
+    int nblk;
+    StackBlk b0;      // block 0 of the run
+    StackStride st;
+    const float* x_rest;   // y of block 0 minus one y stride: block j >= 1 reads x_rest + j x st.y
+};
+static_assert(sizeof(StackArgs) <= 4096, "StackArgs travels as a kernel argument");
+
 struct TokArgs {
     const float* img;        // [B][S*P][N]
     const float* pre_g; const float* pre_b;     // [P]
@@ -212,6 +232,8 @@ int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr,
                  float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st);   // msst_opt.hip (occupancy probe)
 int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd3.hip (bf16, 8 heads; role split: the default)
+int launch_block_fwd_rs_stack(const StackArgs& a, int grid, hipStream_t st);   // the same for a run of blocks of one stack, ONE launch
+int block_fwd_stack_max_steps();
 int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st);
 bool block_fwd_writes_xn(const BlockArgs& a, int prec);   // does the kernel launch_block_fwd selects honour a.xn_out?
 bool block_fwd_writes_lse(const BlockArgs& a, int prec);  // ... a.lse_out?  (the role-split kernel: bf16, 8 heads, no selection flags)

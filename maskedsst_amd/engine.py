@@ -17,6 +17,7 @@ from .flat import FlatParams
 
 D = 96
 DH = 64
+STACK_MAX_TILES = 12   # msst_block_fwd_stack is used for a stack whose workgroups hold at most this many tiles (crossover measured near 14; batch 256 at the EnMAP shape: 20 / 22)
 MLP = 64
 
 
@@ -250,39 +251,108 @@ class Engine:
 
     def blocks_fwd(self, x0, save=True, drop=(0.0, 0)):
         """run the 2*depth fused blocks; returns (list of activations [x0 .. x_2L], list of x1)"""
-        B = x0.shape[0]
-        S, N, H = self.S, self.N, self.enc.heads
+        H = self.enc.heads
         acts = [x0]
         x1s = []
-        x = x0
         flags = _kernel_flags()
         # bf16 x1 rows (MSST_X1_BF16): only the role-split forward writes them -- bf16, 8 heads, no kernel-selection flags;
         # MSST_X1_BF16=0 keeps fp32 rows.  The x1 tensor's dtype tells the backward which kind it holds.
         x1_bf16 = (save and self.prec == PREC_BF16 and H == 8 and flags == 0 and os.environ.get("MSST_X1_BF16", "1") != "0")
         want_lse = save and self.prec == PREC_BF16 and H == 8 and flags == 0 and os.environ.get("MSST_LSE", "1") != "0"
-        for i, (sname, l) in enumerate(self._layers()):
-            y = torch.empty_like(x)
-            x1 = (torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if x1_bf16 else torch.empty_like(x)) if save else None
-            # bf16: the block also saves LN1(x) as it used it (bf16 rows), if the selected kernel can; the attention backward
-            # then skips its own LN1.  The buffer rides on the x1 tensor object so that every caller keeps its (acts, x1s) pair.
-            xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (save and self.prec != PREC_F32) else None
-            mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
-            # ... and (role-split kernel) the softmax statistics of every (tile, head, row): MSST_LSE=0 keeps the backward's own softmax
-            lse = None
-            if xn is not None and want_lse:
-                lse = torch.empty(int(self.lib.msst_block_lse_floats(mode, B, S, N, H)), dtype=torch.float32, device=x.device)
-            wrote = ctypes.c_int(0)
-            _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
-                                               self.prec | flags | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i, _p(xn), _p(lse),
-                                               ctypes.byref(wrote), _stream()),
-                       "msst_block_fwd")
-            if x1 is not None:
-                x1._msst_xn = xn if (wrote.value & _lib.SAVED_XN) else None
-                x1._msst_lse = lse if (wrote.value & _lib.SAVED_LSE) else None
-            acts.append(y)
-            x1s.append(x1)
-            x = y
+        layers = self._layers()
+        # Round 5: a whole stack (its blocks never mix tiles) as ONE launch of the role-split forward -- msst_block_fwd_stack; same
+        # arithmetic, bit-identical outputs, no prologue + pipeline fill / drain per block.  MSST_FWD_STACK=0: one launch per block.
+        # Measured (tools/fwd_ab.py): ahead when a workgroup holds few tiles (batch 64: -5.5 % forward time, Houston shape: -7.3 %),
+        # behind when it holds many (batch 256, EnMAP shape: +1.3 %) -- MSST_FWD_STACK=1 / 0 force it on / off, otherwise by tiles per workgroup.
+        want_stack = os.environ.get("MSST_FWD_STACK", "auto")
+        stacked = self.prec == PREC_BF16 and H == 8 and flags == 0 and want_stack != "0"
+        i0 = 0
+        while i0 < len(layers):
+            i1 = i0
+            while i1 < len(layers) and layers[i1][0] == layers[i0][0] and i1 - i0 < 16:
+                i1 += 1
+            use = stacked and (want_stack == "1" or self._tiles_per_workgroup(layers[i0][0], x0.shape[0]) <= STACK_MAX_TILES)
+            if not (use and self._fwd_stack(acts, x1s, i0, i1, save, drop, x1_bf16, want_lse)):
+                for i in range(i0, i1):
+                    self._fwd_block(acts, x1s, i, save, drop, x1_bf16, want_lse, flags)
+            i0 = i1
         return acts, x1s
+
+    def _tiles_per_workgroup(self, sname, B):
+        """64-row tiles the busiest workgroup of a block forward walks (the library's own tiling: msst_block_lse_floats counts tiles x heads x 64)"""
+        mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+        tiles = int(self.lib.msst_block_lse_floats(mode, B, self.S, self.N, 1)) // 64
+        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        grid = max(1, min(tiles, ncu, self.max_grid if self.max_grid > 0 else tiles))
+        return -(-tiles // grid)
+
+    def _fwd_block(self, acts, x1s, i, save, drop, x1_bf16, want_lse, flags):
+        """block i as its own launch (msst_block_fwd): appends its output to acts, its saved mid residual to x1s"""
+        x = acts[-1]
+        B = x.shape[0]
+        S, N, H = self.S, self.N, self.enc.heads
+        sname, l = self._layers()[i]
+        y = torch.empty_like(x)
+        x1 = (torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if x1_bf16 else torch.empty_like(x)) if save else None
+        # bf16: the block also saves LN1(x) as it used it (bf16 rows), if the selected kernel can; the attention backward
+        # then skips its own LN1.  The buffer rides on the x1 tensor object so that every caller keeps its (acts, x1s) pair.
+        xn = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if (save and self.prec != PREC_F32) else None
+        mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+        # ... and (role-split kernel) the softmax statistics of every (tile, head, row): MSST_LSE=0 keeps the backward's own softmax
+        lse = None
+        if xn is not None and want_lse:
+            lse = torch.empty(int(self.lib.msst_block_lse_floats(mode, B, S, N, H)), dtype=torch.float32, device=x.device)
+        wrote = ctypes.c_int(0)
+        _lib.check(self.lib.msst_block_fwd(ctypes.byref(self._bw[i]), _p(x), _p(y), _p(x1), mode, B, S, N, H,
+                                           self.prec | flags | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i, _p(xn), _p(lse),
+                                           ctypes.byref(wrote), _stream()),
+                   "msst_block_fwd")
+        if x1 is not None:
+            x1._msst_xn = xn if (wrote.value & _lib.SAVED_XN) else None
+            x1._msst_lse = lse if (wrote.value & _lib.SAVED_LSE) else None
+        acts.append(y)
+        x1s.append(x1)
+
+    def _fwd_stack(self, acts, x1s, i0, i1, save, drop, x1_bf16, want_lse):
+        """blocks i0 .. i1 - 1 (one stack) through msst_block_fwd_stack, one launch; False when the library refuses the call (too many
+        (tile, block) steps per workgroup for its step table, or per-block operands that are not a constant stride apart): the caller
+        then launches block by block"""
+        x0 = acts[-1]
+        B = x0.shape[0]
+        S, N, H = self.S, self.N, self.enc.heads
+        dev = x0.device
+        n = i1 - i0
+        mode = MODE_SPATIAL if self._layers()[i0][0] == "spatial" else MODE_SPECTRAL
+        # one allocation per kind, block j its j-th slice: the kernel addresses block j's operands as block 0's + j x a byte stride
+        # (the weight copies and the flat parameters are laid out that way by _build_weight_storage / FlatParams)
+        def slices(dtype, shape=None):
+            t = torch.empty((n,) + tuple(shape if shape is not None else x0.shape), dtype=dtype, device=dev)
+            return [t[j] for j in range(n)]
+        ys = slices(x0.dtype)
+        x1 = slices(torch.bfloat16 if x1_bf16 else torch.float32) if save else None
+        xn = slices(torch.bfloat16) if save else None
+        lse = slices(torch.float32, (int(self.lib.msst_block_lse_floats(mode, B, S, N, H)),)) if (save and want_lse) else None
+        wv = (ctypes.POINTER(MsstBlockWeights) * n)(*[ctypes.pointer(self._bw[i0 + j]) for j in range(n)])
+        VP = ctypes.c_void_p * n
+
+        def arr(ts):
+            return VP(*[t.data_ptr() for t in ts]) if ts is not None else None
+        wrote = ctypes.c_int(0)
+        rc = self.lib.msst_block_fwd_stack(wv, n, _p(x0), arr(ys), arr(x1), arr(xn), arr(lse), mode, B, S, N, H,
+                                           self.prec | (_lib.X1_BF16 if x1_bf16 else 0), self.max_grid, drop[0], drop[1], i0,
+                                           ctypes.byref(wrote), _stream())
+        if rc == -2:   # MSST_ERR_UNSUPPORTED: nothing was launched
+            return False
+        _lib.check(rc, "msst_block_fwd_stack")
+        for j in range(n):
+            acts.append(ys[j])
+            if save:
+                x1[j]._msst_xn = xn[j] if (wrote.value & _lib.SAVED_XN) else None
+                x1[j]._msst_lse = lse[j] if (lse is not None and (wrote.value & _lib.SAVED_LSE)) else None
+                x1s.append(x1[j])
+            else:
+                x1s.append(None)
+        return True
 
     def head_fwd(self, y, img, idx32, want_pred=False):
         B, T, _ = y.shape

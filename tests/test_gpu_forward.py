@@ -114,3 +114,64 @@ def test_strict_tier_sensitivity_to_the_softmax_scale(monkeypatch):
     record("strict_tier_sensitivity", tripped_by_relative_scale_error={str(k): v for k, v in tripped.items()})
     assert not tripped[0.0], tripped            # the unperturbed comparison is inside the tier (same build as the baseline)
     assert tripped[2.0 ** -1], tripped           # a gross scale error is seen
+
+
+STACK_CASES = [
+    dict(bands=200, depth=2, B=5),                                          # 100 / 320 tiles: one tile per workgroup (a lone group, padded with idle steps) or two
+    dict(bands=50, depth=12, B=8),                                          # BASELINE config 2's depth: twelve blocks per launch
+    dict(bands=200, depth=3, B=256),                                        # BASELINE.json's batch: 20 / 22 tiles per workgroup (groups of 3 and 4), odd block count
+    dict(bands=30, depth=2, B=3, image_size=6, mask_patch_size=2),          # 36-token sequences: 28 padding rows per spatial tile
+    dict(bands=70, depth=4, B=3, image_size=4, mask_patch_size=2),          # four spatial sequences per tile
+    dict(bands=200, depth=2, B=70),                                         # 1400 spatial tiles: 5 or 6 per workgroup (a group of 5; two groups of 3)
+]
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+@pytest.mark.parametrize("cfg", STACK_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_stack_forward_is_bit_identical_to_per_block_launches(cfg, dropout, monkeypatch):
+    """msst_block_fwd_stack (round 5: a whole stack as ONE launch of the role-split forward, a workgroup taking its tiles through block
+    after block) against one msst_block_fwd launch per block: the same arithmetic in another order of (tile, block) steps --
+    every block output, every saved row set (x1, LN1 rows) and the softmax statistics must be BIT-identical, with and without
+    dropout, for workgroups that hold one tile (idle steps), a few (one group) or many (several groups)."""
+    model, params, x = build_product(dict(cfg, dropout=dropout), precision="bf16", device="cuda")
+    if dropout:
+        model.train()
+    eng = model.engine()
+    eng.prep_weights()
+    x0 = eng.tokenize(x.cuda(), None)
+    drop = (dropout, 4321) if dropout else (0.0, 0)
+
+    def run(flag):
+        monkeypatch.setenv("MSST_FWD_STACK", flag)
+        acts, x1s = eng.blocks_fwd(x0, save=True, drop=drop)
+        torch.cuda.synchronize()
+        return acts, x1s
+
+    a1, s1 = run("1")
+    a0, s0 = run("0")
+    monkeypatch.delenv("MSST_FWD_STACK")
+    assert len(a1) == len(a0) == 2 * cfg["depth"] + 1
+    for i, (p, q) in enumerate(zip(a1, a0)):
+        assert torch.isfinite(p).all() and torch.equal(p, q), ("block output", i, relerr(p, q))
+    for i, (p, q) in enumerate(zip(s1, s0)):
+        assert p.dtype == q.dtype and torch.equal(p, q), ("x1 rows", i)
+        assert torch.equal(p._msst_xn, q._msst_xn), ("LN1 rows", i)
+        assert torch.equal(p._msst_lse, q._msst_lse), ("softmax statistics", i)
+    # the no-save form (eval / no_grad) too
+    monkeypatch.setenv("MSST_FWD_STACK", "1")
+    e1, _ = eng.blocks_fwd(x0, save=False, drop=drop)
+    monkeypatch.delenv("MSST_FWD_STACK")
+    assert torch.equal(e1[-1], a0[-1])
+
+
+def test_stack_launch_is_chosen_by_tiles_per_workgroup():
+    """the host takes msst_block_fwd_stack for a stack whose workgroups hold few tiles (where the saved launches outweigh the block
+    switches: measured with tools/fwd_ab.py) and one launch per block otherwise; the count it decides on is the library's own tiling"""
+    from maskedsst_amd.engine import STACK_MAX_TILES
+    model, params, x = build_product(dict(bands=200, depth=1, B=2), precision="bf16", device="cuda")
+    eng = model.engine()
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    for B in (2, 64, 256):
+        assert eng._tiles_per_workgroup("spatial", B) == -(-B * 20 // min(B * 20, ncu))       # one 64-token sequence per tile
+        assert eng._tiles_per_workgroup("spectral", B) == -(-(-(-B * 64 // 3)) // min(-(-B * 64 // 3), ncu))   # three 20-token sequences per tile
+    assert eng._tiles_per_workgroup("spatial", 64) <= STACK_MAX_TILES < eng._tiles_per_workgroup("spatial", 256)
