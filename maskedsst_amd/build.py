@@ -30,11 +30,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force=False, verbose=False, extra_flags=()):
-    """extra_flags: e.g. ("-DMSST_STAMPS",) for the kernel-study builds used by tools/stamps*.py"""
+def build(force=False, verbose=False, extra_flags=(), lib=None, tag=None):
+    """extra_flags: e.g. ("-DMSST_STAMPS",) for the kernel-study builds used by tools/stamps*.py.
+    lib / tag: another output library and object directory (build/<tag>/) -- kernel-study variants built NEXT to the product library
+    (tools/gate_qkv.py loads maskedsst_amd/libmsst_lab.so), so that a GPU call does not spend minutes rebuilding"""
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", tag) if tag else os.path.join(HERE, "build")
+    LIB = lib or globals()["LIB"]
     os.makedirs(objdir, exist_ok=True)
     hipcc = _hipcc()
 

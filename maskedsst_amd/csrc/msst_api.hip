@@ -99,8 +99,8 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
 // and nothing else that is shared.  The opt-in profiler state below is guarded by a mutex (records) and is
 // per-thread where a launch is bracketed (the open record), so enabling it never makes a compute call unsafe.
 struct ProfRec { int id; hipEvent_t a, b; };
-#ifdef MSST_STAMPS
-static unsigned long long* g_stamps = nullptr;   // kernel-study builds only (python -m maskedsst_amd.build --stamps)
+#if defined(MSST_STAMPS) || defined(MSST_LAB)
+static unsigned long long* g_stamps = nullptr;   // kernel-study builds only (python -m maskedsst_amd.build --stamps; -DMSST_LAB: the scratch of tools/gate_qkv.py)
 #endif
 static std::atomic<bool> g_prof_on{false};
 static std::atomic<unsigned long long> g_prof_mask{~0ull};   // kernels (bit = id) that get event pairs
@@ -197,7 +197,7 @@ int msst_version(void) { return MSST_VERSION; }
 const char* msst_last_error(void) { return g_err; }
 
 int msst_debug_stamps(void* buf) {
-#ifdef MSST_STAMPS
+#if defined(MSST_STAMPS) || defined(MSST_LAB)
     g_stamps = (unsigned long long*)buf;
     return 0;
 #else
@@ -302,6 +302,8 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
 #ifdef MSST_STAMPS
     a.stamps = g_stamps;
     if (g_stamps) a.dbg = dbg;
+#elif defined(MSST_LAB)
+    a.stamps = g_stamps;
 #endif
     // MSST_X1_BF16: only the role-split forward (bf16, 8 heads, no kernel selection flags) writes bf16 x1 rows
     a.x1_bf16 = (dbg & 1024) ? 1 : 0;
@@ -554,6 +556,8 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
 #ifdef MSST_STAMPS
         aa.stamps = g_stamps;
         if (g_stamps) aa.dbg = dbg;
+#elif defined(MSST_LAB)
+        aa.stamps = g_stamps;
 #endif
         int rc = launch_block_bwd_attn(aa, nc, prec, st, &nparts);
         if (rc) return fail(rc, "msst_block_bwd(attn)");

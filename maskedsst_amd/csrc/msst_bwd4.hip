@@ -444,6 +444,19 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // kernel-study build only (msst_version() < 0, refused by maskedsst_amd/_lib.py): MSST_LAB_EXP & 1 = the q / k / v waves skip
             // their projections (WRONG results: stale tiles) -- what any scheme that hands q / k / v to the backward could gain at most
             if ((MSST_LAB_EXP & 1) && !roleO) { p2a_part(0); p2a_part(1); } else
+#ifdef MSST_LAB_QKV
+            // (tools/gate_qkv.py) ... and with a scratch given, the q / k / v waves fetch their 8 KB tile from it by LDS-DMA instead
+            // (garbage values; never waited for by itself: what a fetch placed a tile ahead would cost in issue slots and HBM traffic)
+            if (a.stamps && !roleO) {
+                p2a_part(0); p2a_part(1);
+                const char* src = reinterpret_cast<const char*>(a.stamps) + ((long)(tile * H + h) * 3 + wave) * 8192 + (t_ & 63) * 16;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const unsigned dst = (unsigned)(size_t)sm + p1_out + i * 1024;
+                    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src + i * 1024) : "memory", "m0");
+                }
+            } else
+#endif
 #endif
             {
             rd1(0); rd1(1); rd1(2);

@@ -458,6 +458,21 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                     }
                 }
                 F3_STAMP(1 + 5 * rd);   // projections done
+#if defined(MSST_LAB) && defined(MSST_LAB_QKV)
+                // kernel-study build only (tools/gate_qkv.py): what handing q / k / v to the backward would cost the forward -- the head's
+                // 24 operand fragments (24.5 KB per tile and head, 1 GB per block at the bench shape) stored to a scratch
+                if (a.stamps && tile >= 0) {
+                    char* qs = reinterpret_cast<char*>(a.stamps) + (long)(tile * H + h) * 24576 + (threadIdx.x & 63) * 16;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int m = 0; m < 2; ++m) {
+                            *reinterpret_cast<frag*>(qs + (2 * t + m) * 1024) = qB[t][m];
+                            *reinterpret_cast<frag*>(qs + 8192 + (2 * t + m) * 1024) = kA[t][m];
+                            *reinterpret_cast<frag*>(qs + 16384 + (2 * t + m) * 1024) = vA[t][m];
+                        }
+                }
+#endif
                 // ---- attention of head h, TWO query tiles at a time, phase by phase: the A wave is alone on its SIMD's VALU most of
                 // the time, so the latency of its own dependent chain (S MFMAs -> max -> exp -> sum -> 1 / x -> dropout -> P V MFMAs ->
                 // pack) is what it waits for; two independent query tiles in flight fill those slots.  O rows go to the round's
