@@ -175,3 +175,40 @@ def test_stack_launch_is_chosen_by_tiles_per_workgroup():
         assert eng._tiles_per_workgroup("spatial", B) == -(-B * 20 // min(B * 20, ncu))       # one 64-token sequence per tile
         assert eng._tiles_per_workgroup("spectral", B) == -(-(-(-B * 64 // 3)) // min(-(-B * 64 // 3), ncu))   # three 20-token sequences per tile
     assert eng._tiles_per_workgroup("spatial", 64) <= STACK_MAX_TILES < eng._tiles_per_workgroup("spatial", 256)
+
+
+def test_stack_launch_refuses_operands_that_are_not_a_constant_stride_apart():
+    """msst_block_fwd_stack addresses block j's operands as block 0's + j x a byte stride; arrays that are not laid out so are refused
+    (MSST_ERR_UNSUPPORTED, nothing launched) -- the engine then launches block by block -- and so are more than 16 blocks"""
+    import ctypes
+    from maskedsst_amd import _lib
+    from maskedsst_amd._lib import MsstBlockWeights, MODE_SPATIAL
+    from maskedsst_amd.engine import _p, _stream
+    model, params, x = build_product(dict(bands=50, depth=3, B=2), precision="bf16", device="cuda")
+    eng = model.engine()
+    eng.prep_weights()
+    x0 = eng.tokenize(x.cuda(), None)
+    n = 3
+    B, S, N, H = 2, eng.S, eng.N, eng.enc.heads
+    wv = (ctypes.POINTER(MsstBlockWeights) * n)(*[ctypes.pointer(eng._bw[j]) for j in range(n)])
+    VP = ctypes.c_void_p * n
+    buf = torch.empty((5,) + tuple(x0.shape), dtype=torch.float32, device="cuda")
+
+    def call(slots, nblk=n, w=wv):
+        ys = VP(*[buf[s].data_ptr() for s in slots])
+        return eng.lib.msst_block_fwd_stack(w, nblk, _p(x0), ys, None, None, None, MODE_SPATIAL, B, S, N, H, eng.prec, 0, 0.0, 0, 0, None, _stream())
+
+    assert call([0, 1, 2]) == 0          # contiguous slices
+    assert call([0, 2, 4]) == 0          # any constant stride
+    assert call([4, 2, 0]) == 0          # ... also a negative one
+    torch.cuda.synchronize()
+    ref = buf[0].clone()
+    assert call([0, 1, 3]) == -2         # not affine: refused
+    assert b"constant stride" in eng.lib.msst_last_error()
+    wswap = (ctypes.POINTER(MsstBlockWeights) * n)(ctypes.pointer(eng._bw[0]), ctypes.pointer(eng._bw[2]), ctypes.pointer(eng._bw[1]))
+    assert call([0, 1, 2], w=wswap) == -2   # weight copies out of order
+    torch.cuda.synchronize()
+    # the three accepted layouts computed the same thing (block 0's output of the last accepted call sits in slot 4)
+    acts, _ = eng.blocks_fwd(x0, save=False)
+    assert torch.equal(buf[4], acts[1]) and torch.equal(buf[0], acts[3])
+    assert torch.equal(ref, acts[3])
