@@ -60,5 +60,10 @@ rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --step
 python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1 || true; cat $OUT/dp_overlap.txt
 find $OUT/dp -name "*.csv" -size +512k -delete
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gate_microbench.hip -o /tmp/gate_microbench && timeout 120 /tmp/gate_microbench > $OUT/gate_microbench.jsonl || true
+# one launch per stack against one per block (the engine picks by tiles per workgroup), both forms alternating in one process
+( python3 tools/fwd_ab.py | tail -1; python3 tools/fwd_ab.py --batch 64 | tail -1; python3 tools/fwd_ab.py --bands 50 | tail -1 ) > $OUT/fwd_stack_ab.txt 2>/dev/null || true
+cat $OUT/fwd_stack_ab.txt
+# q / k / v handed to the backward through HBM instead of recomputed: kernel-study library built next to the product one (tools/gate_qkv.py)
+if [ -f maskedsst_amd/libmsst_lab.so ]; then timeout 300 python3 tools/gate_qkv.py 2>/dev/null | grep -v Warning > $OUT/gate_qkv.txt || true; cat $OUT/gate_qkv.txt; fi
 cp "gpurun_out/parity_$TAG.jsonl" $OUT/parity_measured.jsonl 2>/dev/null || true
 ls -la $OUT | head -40

@@ -49,7 +49,8 @@ with open(os.path.join(DST, f"{tag}_pmc_summary.txt"), "w") as f:
         f.write(open(os.path.join(SRC, n)).read())
 for n, dst in (("dp_overlap.txt", f"{tag}_dp_overlap.txt"), ("parity_measured.jsonl", f"{tag}_parity_measured.jsonl"),
                ("gpu_tests.txt", f"{tag}_gpu_tests.txt"), ("peak_microbench.json", f"{tag}_peak_microbench.json"),
-               ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl"), ("gate_microbench.jsonl", f"{tag}_gate_microbench.jsonl")):
+               ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl"), ("gate_microbench.jsonl", f"{tag}_gate_microbench.jsonl"),
+               ("fwd_stack_ab.txt", f"{tag}_fwd_stack_ab.txt"), ("gate_qkv.txt", f"{tag}_gate_qkv.txt")):
     if os.path.exists(os.path.join(SRC, n)):
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, dst))
 print(json.dumps(kern, indent=1))
