@@ -46,6 +46,12 @@
 #if defined(MSST_LAB) && !defined(MSST_LAB_EXP)
 #define MSST_LAB_EXP 0
 #endif
+#ifndef MSST_B4_DSFORM
+#define MSST_B4_DSFORM 1   // dS as Pd o dPd - P delta (0: P o (dPd o dm - delta))
+#endif
+#ifndef MSST_B4_DTREE
+#define MSST_B4_DTREE 1   // delta's sixteen products summed as a tree of packed adds (0: one dependent chain)
+#endif
 #ifndef MSST_B4_ADDMFMA
 #define MSST_B4_ADDMFMA 1   // head B adds head A's staged d(LN1 out) rows through identity MFMAs in front of its phase 4 (0: read - widen - add - round behind it)
 #endif
@@ -672,7 +678,43 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         pd = pd * dm[t];
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
+                    if (MSST_B4_DSFORM) dp[t] = dp[t] * pd;            // Pd o dPd (see below)
                 }
+#if MSST_B4_DSFORM
+                // dS = P o (dP - delta), dP = dPd o dm, delta = sum_key P o dP  ==  Pd o dPd - P delta, delta = sum_key Pd o dPd  (Pd = P o dm:
+                // the dropped probabilities just stored): the products Pd o dPd serve both, dPd is never multiplied by dm -- three
+                // instructions per score instead of four
+                // (a tree over the key tiles, two packed adds per level: summed one by one the sixteen adds are ONE dependent chain, 8.5
+                // cycles each with nothing else left to issue at the end of the phase)
+                f32x4 dsum = zero4();
+                {
+                    f32x4 lvl[4];
+                    int n = 0;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) if (on(t)) lvl[n++] = dp[t];
+                    if (!MSST_B4_DTREE) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) if (on(t)) dsum[0] += dp[t][r];
+                    } else if (NM == 0) {   // (run-time tile set: absent tiles hold zeros -- dp was cleared and never multiplied)
+                        dsum = (dp[0] + dp[1]) + (dp[2] + dp[3]);
+                    } else {
+                        dsum = n == 4 ? (lvl[0] + lvl[1]) + (lvl[2] + lvl[3]) : n == 3 ? (lvl[0] + lvl[1]) + lvl[2] : n == 2 ? lvl[0] + lvl[1] : lvl[0];
+                    }
+                }
+                float delta = -colgroup_sum((dsum[0] + dsum[1]) + (dsum[2] + dsum[3]));
+                // dS WITHOUT the softmax scale (dim_head^-0.5 = 2^-3, exact in bf16): it is folded into the q / k blocks of the
+                // phase-4 weights (msst_prep_weights, pack = 2) and into the dWq / dWk slabs at the end of the kernel
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    if (!on(t)) { lds_w64(sm, R3_DS + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
+                    f32x4 d4;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) d4[r] = fmaf(pr[t][r], delta, dp[t][r]);
+                    lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
+                }
+#else
                 float delta = 0.f;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -692,6 +734,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta);
                     lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
+#endif
             };
             {
                 if (L == 64) softmax_phase(std::integral_constant<int, -1>{});
