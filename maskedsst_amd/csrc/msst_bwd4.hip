@@ -49,6 +49,12 @@
 #ifndef MSST_B4_DSFORM
 #define MSST_B4_DSFORM 1   // dS as Pd o dPd - P delta (0: P o (dPd o dm - delta))
 #endif
+#ifndef MSST_B4_P1TILE
+#define MSST_B4_P1TILE 0   // 1: phase 1 C tile by C tile like MSST_B4_P3TILE (six dependent MFMAs per accumulator, six row fragments held): measured +0.8 %, off
+#endif
+#ifndef MSST_B4_P3TILE
+#define MSST_B4_P3TILE 1   // phase 3 C tile by C tile, a tile's conversion + stores under the next tile's MFMAs (0: d tile 0's under d tile 1's)
+#endif
 #ifndef MSST_B4_DTREE
 #define MSST_B4_DTREE 1   // delta's sixteen products summed as a tree of packed adds (0: one dependent chain)
 #endif
@@ -464,6 +470,33 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             } else
 #endif
 #endif
+#if MSST_B4_P1TILE
+            {
+                // C tile by C tile -- (d 0, row tile 0), (d 1, 0), (d 0, 1), (d 1, 1), six MFMAs each -- a tile's conversion + LDS stores
+                // under the MFMAs of the next: only the last tile's twelve instructions are left behind the last MFMA (row-tile-major it
+                // was two tiles' worth).  The six row fragments of a row tile stay in registers for both of its d tiles; a slot is
+                // refilled with the other row tile's fragment right behind its last use.
+                s16x8 fr[6];
+                auto rdr = [&](int rt, int ks) { fr[ks] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + rt * 32 * 192); };
+                auto ept = [&](int dt, int rt, int q4) { lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4)); };
+                rdr(0, 0); rdr(0, 1); rdr(0, 2);
+#pragma unroll
+                for (int st = 0; st < 24; ++st) {
+                    const int tl = st / 6, ks = st % 6, dt = tl & 1, rt = tl >> 1;
+                    if (tl == 0 && ks + 3 < 6) rdr(0, ks + 3);
+                    MSST_SCHED_FENCE();
+                    c[dt][rt] = mma32(w1[dt][ks], fr[ks], c[dt][rt]);
+                    if (tl == 1) rdr(1, ks);
+                    if (st == 2) p2a_part(0);
+                    if (st == 3) p2a_part(1);
+                    if (tl >= 1 && ks >= 1 && ks <= 4) ept((tl - 1) & 1, (tl - 1) >> 1, ks - 1);
+                    MSST_SCHED_FENCE();
+                }
+                R4_STAMP(12);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) ept(1, 1, q4);
+            }
+#else
             {
             rd1(0); rd1(1); rd1(2);
 #pragma unroll
@@ -484,6 +517,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int i = 0; i < 8; ++i) ep1(1, i);
             }
+#endif
 #else
             s16x8 fb[3][2];   // LN1(x) / da fragments [slot][row tile], two k-steps ahead of their MFMAs
             swpipe<6, 2>(
@@ -807,6 +841,53 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     asm volatile("" : "+v"(q0[ct][q4]));   // (converted HERE, between the MFMAs: without stores -- wave O -- the compiler sinks the conversions behind the last one)
                     if (WR) lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)), q0[ct][q4]);
                 };
+#if MSST_B4_P3TILE
+                // C tile by C tile -- (row tile 0, d 0), (1, d 0), (0, d 1), (1, d 1), four MFMAs each -- with the conversion + LDS
+                // stores of a tile under the MFMAs of the next (three instructions per MFMA): only the last tile's twelve are left
+                // behind the last MFMA, where the matrix pipe has nothing to hide them under (d-tile-major it was two tiles' worth)
+                s16x4 q1[4];      // bf16 of C tile (row tile 0, d tile 1)
+                auto ep3b = [&](int q4) {
+                    q1[q4] = pk4(c[0][1], q4);
+                    asm volatile("" : "+v"(q1[q4]));
+                    if (WR) lds_w64(sm, (L7 ^ (q4 << 4)) + 4096, q1[q4]);
+                };
+                issue_a(0); issue_a(1);
+#pragma unroll
+                for (int st = 0; st < 16; ++st) {
+                    const int tl = st >> 2, kk = st & 3, ct = tl & 1, dt = tl >> 1;   // tile order: (ct 0, dt 0), (1, 0), (0, 1), (1, 1)
+                    if (st + 2 < 4) issue_a(st + 2);
+                    if (st < 4) fb1[st] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * st, p3_a2 + tr[1][1] + 2048 * st);
+                    MSST_SCHED_FENCE();
+                    c[ct][dt] = mma32(fa[kk][ct], dt ? fb1[kk] : fb0[kk], c[ct][dt]);
+                    if (tl == 1) ep3(0, kk);          // (row tile 0, d 0) under (1, d 0)
+                    if (tl == 2) ep3(1, kk);          // (1, d 0) under (0, d 1)
+                    if (tl == 3) ep3b(kk);            // (0, d 1) under (1, d 1)
+                    MSST_SCHED_FENCE();
+                }
+                R4_STAMP(11);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) {
+                    s16x8 r;
+                    const s16x4 lo = q0[kk >> 1][2 * (kk & 1)], hi4 = q0[kk >> 1][2 * (kk & 1) + 1];
+                    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+                    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+                    pa[0][kk] = r;
+                }
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    s16x8 r;
+                    const s16x4 lo = q1[2 * kk], hi4 = q1[2 * kk + 1];
+                    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+                    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
+                    pa[1][kk] = r;
+                    pa[1][2 + kk] = pk8(c[1][1], kk);
+                }
+                if (WR) {
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) lds_w64(sm, (L7 ^ ((4 + q4) << 4)) + 4096, pk4(c[1][1], q4));
+                }
+            };
+#else
                 issue_a(0); issue_a(1);
 #pragma unroll
                 for (int st = 0; st < 8; ++st) {
@@ -839,6 +920,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                             lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + 4096, pk4(c[ct][1], q4));
                 }
             };
+#endif
             if (wave == 0) phase3(std::integral_constant<int, 0>{});
             else if (wave == 3) phase3(std::integral_constant<int, 1>{});
             else phase3(std::integral_constant<int, 2>{});

@@ -214,11 +214,18 @@ __device__ __forceinline__ float colgroup_sum(float v) {
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// (v_max_f32 spelled out: fmaxf on the swapped words -- opaque integers to the compiler -- gets a canonicalising v_max x, x, x in
+// front of each operand, four more instructions on the softmax's dependent chain)
+__device__ __forceinline__ float vmax_raw(float x, float y) {
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(x), "v"(y));
+    return m;
+}
 __device__ __forceinline__ float colgroup_max(float v) {
     auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    v = vmax_raw(__uint_as_float(a[0]), __uint_as_float(a[1]));
     auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+    return vmax_raw(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 // reduction over the 16 lanes that share one lane group (lanes with equal lane>>4)
 __device__ __forceinline__ float rowgroup_sum(float v) {
