@@ -49,14 +49,8 @@
 #ifndef MSST_B4_DSFORM
 #define MSST_B4_DSFORM 1   // dS as Pd o dPd - P delta (0: P o (dPd o dm - delta))
 #endif
-#ifndef MSST_B4_P1TILE
-#define MSST_B4_P1TILE 0   // 1: phase 1 C tile by C tile like MSST_B4_P3TILE (six dependent MFMAs per accumulator, six row fragments held): measured +0.8 %, off
-#endif
 #ifndef MSST_B4_P3TILE
 #define MSST_B4_P3TILE 1   // phase 3 C tile by C tile, a tile's conversion + stores under the next tile's MFMAs (0: d tile 0's under d tile 1's)
-#endif
-#ifndef MSST_B4_DTREE
-#define MSST_B4_DTREE 1   // delta's sixteen products summed as a tree of packed adds (0: one dependent chain)
 #endif
 #ifndef MSST_B4_ADDMFMA
 #define MSST_B4_ADDMFMA 1   // head B adds head A's staged d(LN1 out) rows through identity MFMAs in front of its phase 4 (0: read - widen - add - round behind it)
@@ -470,33 +464,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             } else
 #endif
 #endif
-#if MSST_B4_P1TILE
-            {
-                // C tile by C tile -- (d 0, row tile 0), (d 1, 0), (d 0, 1), (d 1, 1), six MFMAs each -- a tile's conversion + LDS stores
-                // under the MFMAs of the next: only the last tile's twelve instructions are left behind the last MFMA (row-tile-major it
-                // was two tiles' worth).  The six row fragments of a row tile stay in registers for both of its d tiles; a slot is
-                // refilled with the other row tile's fragment right behind its last use.
-                s16x8 fr[6];
-                auto rdr = [&](int rt, int ks) { fr[ks] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + rt * 32 * 192); };
-                auto ept = [&](int dt, int rt, int q4) { lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4)); };
-                rdr(0, 0); rdr(0, 1); rdr(0, 2);
-#pragma unroll
-                for (int st = 0; st < 24; ++st) {
-                    const int tl = st / 6, ks = st % 6, dt = tl & 1, rt = tl >> 1;
-                    if (tl == 0 && ks + 3 < 6) rdr(0, ks + 3);
-                    MSST_SCHED_FENCE();
-                    c[dt][rt] = mma32(w1[dt][ks], fr[ks], c[dt][rt]);
-                    if (tl == 1) rdr(1, ks);
-                    if (st == 2) p2a_part(0);
-                    if (st == 3) p2a_part(1);
-                    if (tl >= 1 && ks >= 1 && ks <= 4) ept((tl - 1) & 1, (tl - 1) >> 1, ks - 1);
-                    MSST_SCHED_FENCE();
-                }
-                R4_STAMP(12);
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) ept(1, 1, q4);
-            }
-#else
             {
             rd1(0); rd1(1); rd1(2);
 #pragma unroll
@@ -517,7 +484,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int i = 0; i < 8; ++i) ep1(1, i);
             }
-#endif
 #else
             s16x8 fb[3][2];   // LN1(x) / da fragments [slot][row tile], two k-steps ahead of their MFMAs
             swpipe<6, 2>(
@@ -726,12 +692,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     int n = 0;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) if (on(t)) lvl[n++] = dp[t];
-                    if (!MSST_B4_DTREE) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) if (on(t)) dsum[0] += dp[t][r];
-                    } else if (NM == 0) {   // (run-time tile set: absent tiles hold zeros -- dp was cleared and never multiplied)
+                    if (NM == 0) {   // (run-time tile set: absent tiles hold zeros -- dp was cleared and never multiplied)
                         dsum = (dp[0] + dp[1]) + (dp[2] + dp[3]);
                     } else {
                         dsum = n == 4 ? (lvl[0] + lvl[1]) + (lvl[2] + lvl[3]) : n == 3 ? (lvl[0] + lvl[1]) + lvl[2] : n == 2 ? lvl[0] + lvl[1] : lvl[0];
