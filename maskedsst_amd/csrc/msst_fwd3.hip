@@ -43,11 +43,6 @@
 #ifndef MSST_F3_BAND
 #define MSST_F3_BAND 1   // spectral blocks: skip the score tiles outside the band j - 1 .. j + 1 at compile time
 #endif
-#ifndef MSST_F3_KM
-#define MSST_F3_KM 0   // 1: the R waves hash the keep masks of the attention-probability dropout (64-bit row masks in LDS), the A waves only
-                       // AND them in.  Measured: forward 267 -> 290 us -- the R waves' 32 hashes per lane and tile run at their raised
-                       // priority on the same SIMD's VALU and lengthen the q1 / q3 intervals; kept as an experiment switch
-#endif
 #ifndef MSST_F3_GROUP
 #define MSST_F3_GROUP 10   // stack walk: a workgroup's tiles are cut into nmine / MSST_F3_GROUP groups; measured 3: +1.8 %, 6: -1.4 %, 10: -2.5 %, 100: -1.7 % (bench brackets, against per-block launches)
 #endif
@@ -59,10 +54,6 @@
 #endif
 #if defined(MSST_LAB) && !defined(MSST_LAB_X1OLD)
 #define MSST_LAB_X1OLD 0
-#endif
-#ifndef MSST_F3_KMQ
-#define MSST_F3_KMQ 1   // (MSST_F3_KM) where the R waves hash: 1 = at the END of q0 / q2, at priority 0 -- the intervals whose barrier the R waves otherwise
-                        // sit out waiting for the A waves' projections; 0 = in q1 / q3 at the R waves' raised priority (the first version)
 #endif
 #ifndef MSST_F3_RPRIO02
 #define MSST_F3_RPRIO02 MSST_F3_RPRIO   // priority of the R waves in q0 / q2, where they finish early and wait for the A waves (q1 / q3, where the A waves wait for them: MSST_F3_RPRIO)
@@ -97,7 +88,6 @@ struct Fwd3Smem {
     float2 st[4][32];                      // LN2 partial statistics (mean, M2 over 48 features): [R wave][row of its 32]
     unsigned rowmap[64];                   // tile row -> (sequence slot << 16 | position), 0xffff = padding row: tile invariant
     unsigned long long vm[64];             // key-validity mask of a query row: bit k set <=> key row k belongs to the query's sequence (tile invariant)
-    unsigned long long km[MSST_F3_KM ? 2 : 1][MSST_F3_KM ? 8 : 1][64];   // (MSST_F3_KM) keep mask of the attention-probability dropout (site 1): [walk-step parity][head][query row], bit = key
     int seqb[4][64];                       // token of position 0 of every sequence slot, tiles of walk steps k - 1 .. k + 1 (by k & 3)
     float lnp[2][640];                     // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1 of the block of a step; [1]: STACK only (the block a step pipeline
                                            // runs into while the stages behind it still work for the block before)
@@ -581,21 +571,14 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                         }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            // site 1 (MSST_F3_KM: keep bits hashed by the R waves): same masks as drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g)
-                            int klo = -1, khi = -1;
-                            if (DROP && MSST_F3_KM) {
-                                const unsigned long long kmq = sm.km[k & 1][h][(2 * jp + u) * 16 + cq];
-                                klo = (int)(unsigned)kmq; khi = (int)(unsigned)(kmq >> 32);
-                            }
+                            // site 1: drop4(site 1, ((tile H + h) 64 + query) 16 + t 4 + g).  (The R waves hashing the keep bits into 64-bit row
+                            // masks in LDS for the A waves to AND in measured 267 -> 290 us, LABNOTES round 4: their 32 hashes per lane and tile
+                            // lengthen the q1 / q3 intervals.)
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
                                 if (!((NM[u] >> t) & 1u)) continue;
                                 s[u][t] = s[u][t] * inv[u];
-                                if (DROP && MSST_F3_KM) {
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r)
-                                        s[u][t][r] = __int_as_float(__float_as_int(s[u][t][r]) & __builtin_amdgcn_sbfe(t < 2 ? klo : khi, 16 * (t & 1) + sh0 + r, 1));
-                                } else if (DROP) {
+                                if (DROP) {
                                     s[u][t] = drop4_noscale(drop_k, 1, (unsigned)(((tile * H + h) * 64 + (2 * jp + u) * 16 + cq) * 16 + t * 4 + (sh0 >> 2)), s[u][t]);
                                 }
                             }
@@ -936,33 +919,9 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             for (int i = 0; i < 3; ++i) acc[jj][i] = zero4();
     };
 
-    // keep masks of the attention-probability dropout of walk step k -> km[k & 1]: R lane rt hashes the 16 element groups of
-    // (head, query row) = (2 part + rt / 128 ..., rt % 64): two rows per lane and tile, one per call (part = 0, 1)
-    auto keep_masks = [&](int k, int part) {
-        if (!DROP || !MSST_F3_KM || k >= nsteps) return;
-        int rt = (int)threadIdx.x - 256;
-        asm volatile("" : "+v"(rt));
-        const int hq = part * 256 + rt, hh = hq >> 6, q = hq & 63;   // head 0..7, query row 0..63
-        const unsigned base = (unsigned)(((tile_at(k) * H + hh) * 64 + q) * 16);
-        const unsigned t16 = a.drop.thr << 16;
-        const Drop drop_k = drop_at(k);
-        unsigned w[2] = {0u, 0u};
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                unsigned ha, hb;
-                drop_bits(drop_k, 1, base + (unsigned)(t * 4 + gg), ha, hb);
-                const unsigned bits = (unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
-                                      ((unsigned)(hb >= t16) << 3);
-                w[t >> 1] |= bits << (16 * (t & 1) + 4 * gg);
-            }
-        sm.km[k & 1][hh][q] = (unsigned long long)w[0] | ((unsigned long long)w[1] << 32);
-    };
     // ---- prologue: LN1 of the first tile ----
     request_ln1(0);
     ln1(0);
-    keep_masks(0, 0); keep_masks(0, 1);
     zero_acc();
     request_fw(0, 0);   // (a definition on every path: step 0 has no out-projection in q0)
     __syncthreads();   // (P1)
@@ -997,7 +956,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             if (lnp_switch && rt < 96) lnp_regs = fetch_lnp(blk_at(k + 1), rt);
         }
         if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); }
-        if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 0); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(2);
         // STACK: every memory operation of this wave so far -- the y / x1 rows the steps before stored above all: LN1 of the same tile's
         // NEXT block requests them in q2 of this step at the earliest -- and the MLP weight copy of this interval have completed
@@ -1010,7 +968,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
         // ---------------- q1 ----------------
         if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);
         if (have_prev) ln2(k - 1);
-        if (!MSST_F3_KMQ) keep_masks(k + 1, 0);
         if (rt < 64) fill_seq(k + 2, rt);   // (first read in q1 of the next step: LN1 request of step k + 2)
         if (have_cur) zero_acc();
         request_fw(0, have_cur ? k : k - 1);
@@ -1025,14 +982,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
         if (have_prev) { store_x1_bf16(k - 1); mlp1(k - 1); }
         if (MSST_F3_LN1Q == 2 && k + 1 < nsteps) ln1(k + 1);
         if (MSST_F3_LN1Q == 3 && k + 1 < nsteps) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
-        if (MSST_F3_KM && MSST_F3_KMQ) { __builtin_amdgcn_s_setprio(0); keep_masks(k + 1, 1); __builtin_amdgcn_s_setprio(MSST_F3_RPRIO); }
         F3_STAMP(7);
         lds_barrier();
         F3_STAMP(8);
         // ---------------- q3 ----------------
         if (MSST_F3_RPRIO02 != MSST_F3_RPRIO) __builtin_amdgcn_s_setprio(MSST_F3_RPRIO);
         if (have_prev) mlp2(k - 1);
-        if (!MSST_F3_KMQ) keep_masks(k + 1, 1);
         F3_STAMP(9);
         if (MSST_F3_LN1Q == 3 && k + 1 < nsteps) ln1(k + 1);
         request_fw(1, have_cur ? k : k - 1);
