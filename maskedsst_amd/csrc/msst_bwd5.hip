@@ -36,10 +36,6 @@
 #ifndef MSST_B5_PASSPIPE
 #define MSST_B5_PASSPIPE 1
 #endif
-#ifndef MSST_B5_TOUCH
-#define MSST_B5_TOUCH 0     // the L waves pull the x1 rows of walk step k + 2 towards this XCD's L2 (one 4-byte LDS-DMA per 128-byte line, no
-                            // registers) when they request their own rows: the M waves' request one step later is then an L2 hit
-#endif
 #ifndef MSST_B5_PRIO
 #define MSST_B5_PRIO 0   // 1: the M waves (the critical chain) run at s_setprio 1 against the L wave that shares their SIMD
 #endif
@@ -68,7 +64,6 @@ struct LmSmem {
     float dxf[2][64][LDF];   // dx_i (fp32) of the tile the M waves process now / next, by walk-step parity
     float out[64][LDF];      // dx1 of block i - 1 (fp32) of the tile the M waves just finished: the L waves copy it out as whole rows
     float gam1[96];          // ln1_g of block i
-    float touch_pad[64];     // landing area of the L2-touch loads (never read)
     int qt[8];               // (QUEUE) tile of walk step k at [k & 7]
     float lnp[256];          // ln2_g | ln2_b | b1 of block i - 1
     char wl[36 * 1024];      // [w1 12 | w2T 12 | w1T 12] fragments of 1 KB (block i - 1)
@@ -173,12 +168,6 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
                     pa[ps][k2] = __builtin_amdgcn_raw_buffer_load_b128(rs_p, vp1, k2 * pstride, 0);
                     pb[ps][k2] = __builtin_amdgcn_raw_buffer_load_b64(rs_p, vp2, k2 * pstride, 0);
                 }
-            }
-            if (MSST_B5_TOUCH && live && ps0 == 0) {
-                // 64 rows x 384 B of x1 = 192 lines of 128 B: lanes 0..47 of each L wave take one line each
-                const long line = (long)tile_ * 192 + lw * 48 + (l < 48 ? l : 47);
-                const long last = (a.ntok * 384 - 1) >> 7;
-                l2_touch(reinterpret_cast<const char*>(a.x1) + ((line < last ? line : last) << 7), sm.touch_pad);
             }
         };
         // dx of tile k -> sm.dxf[k & 1] (the M waves read that buffer during walk step k, the other one during step k - 1)
