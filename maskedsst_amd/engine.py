@@ -67,6 +67,7 @@ class Engine:
         self.tok_chunks = int(os.environ.get("MSST_TOK_CHUNKS", "64"))
         self.bucket_hook = None  # callable(bucket_name, start, end) fired when a gradient bucket is complete
         self.tile_queue = False  # data parallel: the backward's persistent grids draw tiles from a queue (no static partition)
+        self._tpw = {}   # (mode, batch) -> tiles per workgroup of a block forward
         self._wbuf = None
         self._jobs = None
         self._bw = None
@@ -281,10 +282,13 @@ class Engine:
     def _tiles_per_workgroup(self, sname, B):
         """64-row tiles the busiest workgroup of a block forward walks (the library's own tiling: msst_block_lse_floats counts tiles x heads x 64)"""
         mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
-        tiles = int(self.lib.msst_block_lse_floats(mode, B, self.S, self.N, 1)) // 64
-        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-        grid = max(1, min(tiles, ncu, self.max_grid if self.max_grid > 0 else tiles))
-        return -(-tiles // grid)
+        key = (mode, B)
+        hit = self._tpw.get(key)
+        if hit is None:
+            tiles = int(self.lib.msst_block_lse_floats(mode, B, self.S, self.N, 1)) // 64
+            grid = max(1, min(tiles, self._cu_count(), self.max_grid if self.max_grid > 0 else tiles))
+            hit = self._tpw[key] = -(-tiles // grid)
+        return hit
 
     def _fwd_block(self, acts, x1s, i, save, drop, x1_bf16, want_lse, flags):
         """block i as its own launch (msst_block_fwd): appends its output to acts, its saved mid residual to x1s"""
