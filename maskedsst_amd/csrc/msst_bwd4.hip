@@ -34,29 +34,8 @@
 #ifndef MSST_B3_W1AT
 #define MSST_B3_W1AT 8   // phase-4 step behind which the next tile's phase-1 weights are requested (>= 6: behind the last phase-4 weight request)
 #endif
-#ifndef MSST_B4_HASH_P1
-#define MSST_B4_HASH_P1 1   // the attention-probability dropout hash of all four key tiles is issued at the top of the softmax phase (0: per key tile, behind the softmax)
-#endif
-#ifndef MSST_B4_SPLIT
-#define MSST_B4_SPLIT 3   // 1: phase 1, 2: phase 3 -- half of a GEMM phase's C tiles first, their conversion + LDS stores between the MFMAs of the other half
-#endif
-#ifndef MSST_B4_DMDIRECT
-#define MSST_B4_DMDIRECT 1   // the dropout multipliers of the attention probabilities are produced where their hash is (top of the softmax phase)
-#endif
 #if defined(MSST_LAB) && !defined(MSST_LAB_EXP)
 #define MSST_LAB_EXP 0
-#endif
-#ifndef MSST_B4_DSFORM
-#define MSST_B4_DSFORM 1   // dS as Pd o dPd - P delta (0: P o (dPd o dm - delta))
-#endif
-#ifndef MSST_B4_P3TILE
-#define MSST_B4_P3TILE 1   // phase 3 C tile by C tile, a tile's conversion + stores under the next tile's MFMAs (0: d tile 0's under d tile 1's)
-#endif
-#ifndef MSST_B4_ADDMFMA
-#define MSST_B4_ADDMFMA 1   // head B adds head A's staged d(LN1 out) rows through identity MFMAs in front of its phase 4 (0: read - widen - add - round behind it)
-#endif
-#ifndef MSST_B4_WGPRE
-#define MSST_B4_WGPRE 0   // steps (of 12) of the weight-gradient GEMM in front of barrier B3
 #endif
 #ifndef MSST_B4_LAG
 #define MSST_B4_LAG 2   // barriers head B runs behind head A (1 or 2; 3 would need a second OUT buffer)
@@ -126,12 +105,6 @@ __device__ __forceinline__ s16x8 pk8(const f32x16& c, int k0) {
     r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
     return r;
 }
-// 1 KB fragment f of a fragment-packed (32 rows x 16 k per fragment) bf16 matrix: descriptor and fragment offset are
-// wave uniform, the lane offset is shared by all weight loads
-__device__ __forceinline__ s16x8 ld_w32(const void* w, int f, int lane16) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(w), 0, 0x7fffffff, 0x00020000);
-    return __builtin_bit_cast(s16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, f * 1024, 0));
-}
 // the same with the fragment offset split into a wave-uniform base (SGPR) and a small constant that rides in the instruction's 12-bit
 // offset field (< 4 KB: four fragments per base).  One SGPR per FOUR fragments instead of one per fragment: with twelve phase-1 and
 // twelve phase-4 fragment offsets precomputed, the register allocator parked two dozen of them in VGPR lanes and every request paid a
@@ -144,9 +117,6 @@ __device__ __forceinline__ int launder_s(int v) {
     asm volatile("" : "+s"(v));
     return v;
 }
-#ifndef MSST_B4_WBASE
-#define MSST_B4_WBASE 1   // weight fragment requests as base + immediate (0: one precomputed offset per fragment)
-#endif
 // 16 bytes per lane, global -> LDS without passing registers: lane i's bytes land at lds_dst + 16 i (lds_dst wave uniform, below
 // 64 KB); a lane whose offset lies outside the descriptor writes zeros.  Opaque to the compiler's vmcnt bookkeeping (the builtin
 // form makes every later LDS read wait for vmcnt(0)): loads return in order, so the compiler's own waits only become more
@@ -165,7 +135,7 @@ __device__ __forceinline__ int launder3(int v) {
 // k-step f of a 32 x 32 bf16 identity as an A operand fragment (32 rows x 16 k; lane = 32 (k / 8 % 2) + row, 8 consecutive k per
 // lane): element e of lane (row i, half hi) is 1.0 where 16 f + 8 hi + e == i.  Head B's phase 4 starts from head A's staged rows
 // through two such MFMAs per row tile -- C[m][row] = sum_k I[m][k] staged[row][k], exact -- instead of reading, widening and
-// adding them on the VALU behind its own MFMAs (MSST_B4_ADDMFMA).  Built on the VALU (a dozen instructions per fragment): as a
+// adding them on the VALU behind its own MFMAs (read - widen - add - round: 64 VALU + 8 LDS instructions more per head-B wave and tile).  Built on the VALU (a dozen instructions per fragment): as a
 // table in memory the two loads sink to their only use and the phase starts with an L2 round trip.
 __device__ __forceinline__ s16x8 ident32_frag(int f, int i, int hi) {
     const int e = i - 16 * f - 8 * hi;                                  // 0 .. 7 where this lane holds the 1
@@ -246,13 +216,10 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         need = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
     }
     // row-wise LDS address of this thread's j-th 16-byte slot in a 96-wide tile: row tid / 4, logical slot 4 j + tid % 4 -- the four
-    // threads of a row cover 64 contiguous bytes per store instruction (MSST_B4_COSEG = 0: 3 (tid % 4) + j, 16-byte pieces 48 bytes apart)
-#ifndef MSST_B4_COSEG
-#define MSST_B4_COSEG 1
-#endif
+    // threads of a row cover 64 contiguous bytes per store instruction (3 (tid % 4) + j -- 16-byte pieces 48 bytes apart -- was round 3's)
     auto row_slot = [&](int j) -> unsigned {
         const int t_ = launder3(tid);
-        const int row = t_ >> 2, s = MSST_B4_COSEG ? 4 * j + (t_ & 3) : 3 * (t_ & 3) + j;
+        const int row = t_ >> 2, s = 4 * j + (t_ & 3);
         return (unsigned)(row * 192 + (((s & ~3) | ((s & 3) ^ fz2(row))) << 4));
     };
     // The LN1(x) / da rows of the NEXT tile go straight from HBM into the other row buffer (LDS-DMA, head A's waves: 1 KB per
@@ -329,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
     {
         const unsigned sp = rowmap[tid >> 2];
         csx = (unsigned)(R4_SEQO + 4 * min((int)(sp >> 16), 64));
-        cinv = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)(tid & 3) * (MSST_B4_COSEG ? 16u : 48u);
+        cinv = (sp & 0xffffu) * (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N) + (unsigned)(tid & 3) * 16u;
     }
     auto copy_out = [&]() {
         const int bs = *reinterpret_cast<const __attribute__((address_space(3))) int*>(sm + csx);
@@ -339,32 +306,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(a.ntok * 192), 0x00020000);
         const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + cinv;   // (+ 128 must not wrap)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + (MSST_B4_COSEG ? 64 : 16) * j, 0, 0);
+        for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 64 * j, 0, 0);
     };
-    // The same copy-out by ONE wave (wave O of head A, at the end of its phase 3: it has no phase 4 and sits out ~1.5 k cycles in
-    // front of barrier B3, while head B's phase 1 -- where the copy-out used to be -- is the longest stretch of ITS interval; cycle
-    // stamps, LABNOTES round 4): four passes of 16 rows, a lane <-> 16 bytes of a row's 64-byte piece, three pieces per row.
-#ifndef MSST_B4_COW
-#define MSST_B4_COW 2   // 0: head B, behind its phase 1 (round 3); 1: wave O of head A alone at the end of its phase 3 (1.3 k cycles for one wave: it becomes the last arriver); 2: all four waves of head A there, a quarter each (-0.5 %)
-#endif
-    auto copy_out_wave = [&]() {
-        const int l_ = launder3(tid) & 63;
-        const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(part, 0, (int)(a.ntok * 192), 0x00020000);
-        const unsigned rstride = (unsigned)(tm.mode == 0 ? 192 : 192 * tm.N);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = 16 * p + (l_ >> 2);
-            const unsigned sp = rowmap[row];
-            const int bs = seqout[min((int)(sp >> 16), 64)];
-            const unsigned voff = bs < 0 ? 0x80000000u : (unsigned)bs * 192u + (sp & 0xffffu) * rstride + (unsigned)(l_ & 3) * 16u;
-            u32x4 v[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                v[j] = *reinterpret_cast<const lds_u32x4*>(sm + R4_OUT + row * 192 + (((4 * j) | ((l_ & 3) ^ fz2(row))) << 4));
-#pragma unroll
-            for (int j = 0; j < 3; ++j) __builtin_amdgcn_raw_buffer_store_b128(v[j], rp, voff + 64 * j, 0, 0);
-        }
-    };
+    // (Who copies out, measured in round 4: head B behind its phase 1 -- the longest stretch of ITS interval; wave O of head A alone at
+    // the end of its phase 3 -- 1.3 k cycles for one wave, it becomes the last arriver; all four waves of head A there, a quarter
+    // each: -0.5 %, kept.)
     // phase-1 weight fragments [d tile][k step]: tile invariant, but 48 registers the softmax phase has no room for -- all twelve
     // are re-requested from L2 during phase 4 of the tile before (the rows no longer pass registers: a ring of eight refilled
     // inside phase 1 left its last two k-steps waiting on L2)
@@ -377,8 +323,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int ks = 0; ks < 6; ++ks) {
                 const int fi = 6 * dt + ks;
-                if (MSST_B4_WBASE) w1[dt][ks] = ld_w32b(w1p, b1 + (fi >> 2) * 4096, (fi & 3) * 1024, l16);
-                else w1[dt][ks] = ld_w32(w1p, f1_0 + fi, l16);
+                w1[dt][ks] = ld_w32b(w1p, b1 + (fi >> 2) * 4096, (fi & 3) * 1024, l16);   // (base + immediate: one precomputed offset per fragment cost registers)
             }
     };
     load_w1();
@@ -402,7 +347,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #endif
         R4_STAMP(0);
         B4_PRIO(1);
-        unsigned keepm = 0;   // keep decisions of the attention-probability dropout (site 1) of this lane's 16 scores of phase 2, bit 4 t + r
         unsigned p2a[4];   // the softmax phase's lane addresses and first key of the lane's sequence, computed under phase 1's MFMAs as well
         // ---------------- phase 1: q | k | v | dO = rows . W^T  (C[i = channel][j = row], stored [row][channel]) ----------------
         {
@@ -417,7 +361,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) c[i][j] = zero16();
-#if MSST_B4_SPLIT & 1
             // Row tile 0 first, then row tile 1 (twelve MFMAs each): the conversion + LDS stores of row tile 0's two C tiles and the
             // softmax phase's lane addresses issue BETWEEN the MFMAs of row tile 1 (a 32x32x16 MFMA hides four single-issue
             // instructions of its own wave) instead of all 64 values of the four C tiles behind the last MFMA, where both waves of
@@ -484,41 +427,8 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
             for (int i = 0; i < 8; ++i) ep1(1, i);
             }
-#else
-            s16x8 fb[3][2];   // LN1(x) / da fragments [slot][row tile], two k-steps ahead of their MFMAs
-            swpipe<6, 2>(
-                [&](int ks) {
-                    fb[ks % 3][0] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1));
-                    fb[ks % 3][1] = lds_r128(sm, bin[ks & 1] + 64 * (ks >> 1) + 32 * 192);
-                },
-                [&](int ks) {
-                    c[0][0] = mma32(w1[0][ks], fb[ks % 3][0], c[0][0]);
-                    c[0][1] = mma32(w1[0][ks], fb[ks % 3][1], c[0][1]);
-                    c[1][0] = mma32(w1[1][ks], fb[ks % 3][0], c[1][0]);
-                    c[1][1] = mma32(w1[1][ks], fb[ks % 3][1], c[1][1]);
-                });
-            R4_STAMP(12);
-            {
-                const int l = t_ & 63, g = l >> 4, c16 = l & 15, fzc = fz(c16);
-                p2a[0] = gb + c16 * 128 + ((g ^ fzc) << 4);          // (gb: no bits below 16 K, commutes with the XORs)
-                p2a[1] = gb + c16 * 128 + (((4 + g) ^ fzc) << 4);
-                p2a[2] = gb + (16 * wave + c16) * 128 + (((g >> 1) ^ fzc) << 4) + 8 * (g & 1);
-                p2a[3] = (unsigned)(16 * wave + c16 - (int)(rowmap[16 * wave + c16] & 0xffffu));
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(p2a[i]));
-            }
-            const unsigned L7 = p1_out + l31 * 128 + (fz(l31) << 4) + 8 * hi;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        lds_w64(sm, (L7 ^ ((4 * dt + q4) << 4)) + rt * 4096, pk4(c[dt][rt], q4));
-#endif
         }
         // (copy-out placed behind phase 1's MFMAs: in front of them the stores sat in vmcnt order before the phase's weight requests)
-        if (!MSST_B4_COW && grp && ks != 0) copy_out();
         R4_STAMP(1);
         bar3();   // B1
         R4_STAMP(2);
@@ -556,23 +466,18 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // The dropout hash needs no data: all four key tiles' keep bits first, while the phase's operand reads are in flight,
             // instead of 12 quarter-rate multiplies inside the dependent chain max -> exp -> sum -> P.  (Issued under phase 1's MFMAs
             // -- the VALU is idle there too -- it cost 2 %: phase 1 is on the critical path of its barrier interval.)
-            if (DROP && MSST_B4_HASH_P1) {
+            if (DROP) {
                 const unsigned t16 = a.drop.thr << 16;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     unsigned ha, hb;
                     drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
-#if MSST_B4_DMDIRECT
                     // the multipliers themselves (0 or 1 / (1 - p)), one compare + one select per score, instead of keep bits packed into
                     // a word here and unpacked (and + compare + select per score) behind the softmax: ~70 instructions per wave and tile
                     dm[t][0] = (ha << 16) >= t16 ? a.drop.scale : 0.f;
                     dm[t][1] = ha >= t16 ? a.drop.scale : 0.f;
                     dm[t][2] = (hb << 16) >= t16 ? a.drop.scale : 0.f;
                     dm[t][3] = hb >= t16 ? a.drop.scale : 0.f;
-#else
-                    keepm |= ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
-                              ((unsigned)(hb >= t16) << 3)) << (4 * t);
-#endif
                 }
             }
             // NM: -1 = one 64-token sequence, nothing masked; > 0 = short sequences, the key tiles of this wave known at compile
@@ -665,22 +570,11 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     if (!on(t)) { lds_w64(sm, R3_P + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
                     f32x4 pd = pr[t];   // site 1: O and dV see the dropped probabilities, the softmax backward the raw ones
                     if (DROP) {
-                        if (!MSST_B4_HASH_P1) {
-                            unsigned ha, hb;
-                            drop_bits(a.drop, 1, (unsigned)(((tile * H + h) * 64 + wave * 16 + c16) * 16 + t * 4 + g), ha, hb);
-                            const unsigned t16 = a.drop.thr << 16;
-                            keepm = ((unsigned)((ha << 16) >= t16) | ((unsigned)(ha >= t16) << 1) | ((unsigned)((hb << 16) >= t16) << 2) |
-                                     ((unsigned)(hb >= t16) << 3)) << (4 * t);
-                        }
-                        if (!(MSST_B4_DMDIRECT && MSST_B4_HASH_P1))
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) dm[t][r] = (keepm >> (4 * t + r)) & 1u ? a.drop.scale : 0.f;
                         pd = pd * dm[t];
                     }
                     lds_w64(sm, R3_P + (L8 ^ (t << 5)), f2bf4(pd));   // P[query][key]
-                    if (MSST_B4_DSFORM) dp[t] = dp[t] * pd;            // Pd o dPd (see below)
+                    dp[t] = dp[t] * pd;            // Pd o dPd (see below)
                 }
-#if MSST_B4_DSFORM
                 // dS = P o (dP - delta), dP = dPd o dm, delta = sum_key P o dP  ==  Pd o dPd - P delta, delta = sum_key Pd o dPd  (Pd = P o dm:
                 // the dropped probabilities just stored): the products Pd o dPd serve both, dPd is never multiplied by dm -- three
                 // instructions per score instead of four
@@ -709,27 +603,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     for (int r = 0; r < 4; ++r) d4[r] = fmaf(pr[t][r], delta, dp[t][r]);
                     lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
                 }
-#else
-                float delta = 0.f;
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (!on(t)) continue;
-                    if (DROP) dp[t] = dp[t] * dm[t];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) delta += pr[t][r] * dp[t][r];
-                }
-                delta = colgroup_sum(delta);
-                // dS WITHOUT the softmax scale (dim_head^-0.5 = 2^-3, exact in bf16): it is folded into the q / k blocks of the
-                // phase-4 weights (msst_prep_weights, pack = 2) and into the dWq / dWk slabs at the end of the kernel
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    if (!on(t)) { lds_w64(sm, R3_DS + (L8 ^ (t << 5)), s16x4{0, 0, 0, 0}); continue; }
-                    f32x4 d4;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) d4[r] = pr[t][r] * (dp[t][r] - delta);
-                    lds_w64(sm, R3_DS + (L8 ^ (t << 5)), f2bf4(d4));   // dS[query][key] / scale
-                }
-#endif
             };
             {
                 if (L == 64) softmax_phase(std::integral_constant<int, -1>{});
@@ -768,7 +641,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
 #pragma unroll
                 for (int j = 0; j < 2; ++j) c[ii][j] = zero16();
             s16x8 pa[2][4];   // [d tile][k step]: A operand of the weight-gradient GEMM
-#if MSST_B4_SPLIT & 2
             // d tile 0 first, then d tile 1 (eight MFMAs each): the conversions of d tile 0's C tiles -- the weight-gradient GEMM's A
             // operand and the dq | dk | dv rows of phase 4 -- and their LDS stores issue between the MFMAs of d tile 1.  The stores go
             // over the tile this wave reads as its second operand: every read of it is issued (pass 0) before the first store; a
@@ -802,7 +674,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     asm volatile("" : "+v"(q0[ct][q4]));   // (converted HERE, between the MFMAs: without stores -- wave O -- the compiler sinks the conversions behind the last one)
                     if (WR) lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)), q0[ct][q4]);
                 };
-#if MSST_B4_P3TILE
                 // C tile by C tile -- (row tile 0, d 0), (1, d 0), (0, d 1), (1, d 1), four MFMAs each -- with the conversion + LDS
                 // stores of a tile under the MFMAs of the next (three instructions per MFMA): only the last tile's twelve are left
                 // behind the last MFMA, where the matrix pipe has nothing to hide them under (d-tile-major it was two tiles' worth)
@@ -848,84 +719,9 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     for (int q4 = 0; q4 < 4; ++q4) lds_w64(sm, (L7 ^ ((4 + q4) << 4)) + 4096, pk4(c[1][1], q4));
                 }
             };
-#else
-                issue_a(0); issue_a(1);
-#pragma unroll
-                for (int st = 0; st < 8; ++st) {
-                    const int dt = st >> 2, kk = st & 3;
-                    if (st + 2 < 4) issue_a(st + 2);
-                    if (st < 4) fb1[st] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * st, p3_a2 + tr[1][1] + 2048 * st);
-                    MSST_SCHED_FENCE();
-                    c[0][dt] = mma32(fa[kk][0], dt ? fb1[kk] : fb0[kk], c[0][dt]);
-                    if (dt) ep3(kk >> 1, 2 * (kk & 1));
-                    MSST_SCHED_FENCE();
-                    c[1][dt] = mma32(fa[kk][1], dt ? fb1[kk] : fb0[kk], c[1][dt]);
-                    if (dt) ep3(kk >> 1, 2 * (kk & 1) + 1);
-                    MSST_SCHED_FENCE();
-                }
-                R4_STAMP(11);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    s16x8 r;
-                    const s16x4 lo = q0[kk >> 1][2 * (kk & 1)], hi4 = q0[kk >> 1][2 * (kk & 1) + 1];
-                    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-                    r[4] = hi4[0]; r[5] = hi4[1]; r[6] = hi4[2]; r[7] = hi4[3];
-                    pa[0][kk] = r;
-                    pa[1][kk] = pk8(c[kk >> 1][1], kk & 1);
-                }
-                if (WR) {
-#pragma unroll
-                    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + 4096, pk4(c[ct][1], q4));
-                }
-            };
-#endif
             if (wave == 0) phase3(std::integral_constant<int, 0>{});
             else if (wave == 3) phase3(std::integral_constant<int, 1>{});
             else phase3(std::integral_constant<int, 2>{});
-#else
-            constexpr int D3 = MSST_B3_D3A;
-            s16x8 fa[D3 + 1][2], fb[D3 + 1][2];   // [slot][tile], D3 k-steps ahead
-            auto issue_b = [&](int kk) {
-                fb[kk % (D3 + 1)][0] = lds_tr2(sm, p3_a2 + tr[0][0] + 2048 * kk, p3_a2 + tr[0][1] + 2048 * kk);
-                fb[kk % (D3 + 1)][1] = lds_tr2(sm, p3_a2 + tr[1][0] + 2048 * kk, p3_a2 + tr[1][1] + 2048 * kk);
-            };
-            auto issue_a = [&](int kk) {
-                if (pathX) {
-                    fa[kk % (D3 + 1)][0] = lds_r128(sm, a1 ^ (kk << 5));
-                    fa[kk % (D3 + 1)][1] = lds_r128(sm, (a1 ^ (kk << 5)) + 4096);
-                } else {
-                    fa[kk % (D3 + 1)][0] = lds_tr2(sm, p3_a1 + tr[0][0] + 2048 * kk, p3_a1 + tr[0][1] + 2048 * kk);
-                    fa[kk % (D3 + 1)][1] = lds_tr2(sm, p3_a1 + tr[1][0] + 2048 * kk, p3_a1 + tr[1][1] + 2048 * kk);
-                }
-            };
-#pragma unroll
-            for (int kk = 0; kk < D3; ++kk) issue_b(kk);
-            R4_STAMP(3);
-            bar3();   // B2
-            R4_STAMP(4);
-            if (!grp) { dma_rows(R4_ROWBUF - xb); dma_lse(QUEUE ? __builtin_amdgcn_readfirstlane(qt[(ks + 1) & 3]) : tile + (int)gridDim.x, R4_ROWBUF - xb); }
-            B4_PRIO(3);
-#pragma unroll
-            for (int kk = 0; kk < D3; ++kk) issue_a(kk);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                if (kk + D3 < 4) { issue_a(kk + D3); issue_b(kk + D3); }
-                MSST_SCHED_FENCE();
-                c[0][0] = mma32(fa[kk % (D3 + 1)][0], fb[kk % (D3 + 1)][0], c[0][0]);
-                c[0][1] = mma32(fa[kk % (D3 + 1)][0], fb[kk % (D3 + 1)][1], c[0][1]);
-                c[1][0] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][0], c[1][0]);
-                c[1][1] = mma32(fa[kk % (D3 + 1)][1], fb[kk % (D3 + 1)][1], c[1][1]);
-                MSST_SCHED_FENCE();
-            }
-            R4_STAMP(11);
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) pa[dt][kk] = pk8(c[kk >> 1][dt], kk & 1);
-#endif
             // transposed 32-column fragment of a 96-wide tile in the C-layout row order: k row = 16 kk + 8 a + 4 hi + i / 4
             const unsigned L4 = (4 * hi + (i >> 2)) * 192 + (((2 * u + b) ^ hi) << 4) + 8 * (i & 1);
             unsigned tx[2];
@@ -948,19 +744,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         });
                 }
             };
-#if !(MSST_B4_SPLIT & 2)
-            // dq | dk | dv also go to LDS, transposed ([d][row]), over the tile only this wave read above (k | q | dO)
-            if (!roleO) {
-                const unsigned L7 = p3_a2 + l31 * 128 + (fz(l31) << 4) + 8 * hi;
-#pragma unroll
-                for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-                    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-                            lds_w64(sm, (L7 ^ ((4 * ct + q4) << 4)) + dt * 4096, pk4(c[ct][dt], q4));
-            }
-#endif
             // requests of the weight-gradient GEMM's shadow: the first phase-4 weight fragments (waves Q, K, V), the next tile's rows
             const int l16 = l * 16;
             // (wave O, which has no phase 4, requests one hot fragment six times: a definition on every path keeps the register
@@ -968,24 +751,20 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             // phase-4 fragment k12 = (which, ks): base of `which` (one SGPR each) + 1024 ks in the offset field
             const int b4 = launder_s(roleO ? 0 : f4_0 * 1024), b4s = launder_s(roleO ? 0 : (inner >> 4) * 1024);
             auto ld_w4 = [&](int k12) -> s16x8 {
-                if (MSST_B4_WBASE) return ld_w32b(a.w.wqkvT32, b4 + (k12 >> 2) * b4s, (k12 & 3) * 1024, l16);
-                return ld_w32(a.w.wqkvT32, roleO ? 0 : f4_0 + (k12 >> 2) * (inner >> 4) + (k12 & 3), l16);
+                return ld_w32b(a.w.wqkvT32, b4 + (k12 >> 2) * b4s, (k12 & 3) * 1024, l16);
             };
 #pragma unroll
             for (int k12 = 0; k12 < MSST_B3_W4; ++k12) w4[k12] = ld_w4(k12);
             // copy-out of the tile of the walk step before (complete since barrier B2: head B's phase 4 ran two intervals behind)
-            if (MSST_B4_COW == 1 && wv == 3 && ks != 0) copy_out_wave();
-            if (MSST_B4_COW == 2 && !grp && ks != 0) copy_out();   // (2: all four waves of head A, a quarter each)
-            // MSST_B4_WGPRE of the weight-gradient GEMM's twelve steps run in FRONT of barrier B3 (round 5: with the forward's softmax
-            // statistics the softmax phase that shares the next interval is shorter than weight-gradient GEMM + phase 4)
-            wgrad(std::integral_constant<int, 0>{}, std::integral_constant<int, MSST_B4_WGPRE>{});
+            if (!grp && ks != 0) copy_out();   // (all four waves of head A, a quarter each)
             R4_STAMP(5);
             bar3();   // B3
             R4_STAMP(6);
             B4_PRIO(4);
             // the weight-gradient GEMM runs BEHIND barrier B3 (the rows it reads stay put: the next tile's go to the other row
-            // buffer): phases 1 | 3 and 2 | 4 of the two heads, which share the barrier intervals, are then of equal length
-            wgrad(std::integral_constant<int, MSST_B4_WGPRE>{}, std::integral_constant<int, 12>{});
+            // buffer): phases 1 | 3 and 2 | 4 of the two heads, which share the barrier intervals, are then of equal length.  (Six or
+            // all twelve of its steps in FRONT of the barrier, tried again in round 5 with the shorter softmax phase: +1.7 %.)
+            wgrad(std::integral_constant<int, 0>{}, std::integral_constant<int, 12>{});
             R4_STAMP(9);
             // ---------------- phase 4: d(LN1 out)[row][m] = dq Wq + dk Wk + dv Wv, wave <-> 32 features (waves Q, K, V) ----------------
             if (roleO) {
@@ -994,7 +773,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
             } else {
                 f32x16 c4[2];   // [row tile]: C[i = m][j = row]
                 c4[0] = zero16(); c4[1] = zero16();
-#if MSST_B4_ADDMFMA
                 if (grp) {   // head B: accumulate ONTO head A's rows (staged two intervals ago), exact: 1.0 x bf16 in fp32
                     s16x8 fs[2][2], idf[2];
 #pragma unroll
@@ -1010,7 +788,6 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         c4[1] = mma32(idf[f2], fs[1][f2], c4[1]);
                     }
                 }
-#endif
                 s16x8 fb4[MSST_B3_D4 + 1][2];   // step k12 = (which, ks): dq^T | dk^T | dv^T fragments MSST_B3_D4 steps ahead
                 swpipe<12, MSST_B3_D4>(
                     [&](int k12) {
@@ -1034,32 +811,14 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                     for (int q4 = 0; q4 < 4; ++q4) {
                         const unsigned o = (L9 ^ (q4 << 4)) + rt * 6144;
                         f32x4 t4 = {c4[rt][4 * q4], c4[rt][4 * q4 + 1], c4[rt][4 * q4 + 2], c4[rt][4 * q4 + 3]};
-#ifndef MSST_B4_PKADD
-#define MSST_B4_PKADD 0   // 1: head B adds its rows onto head A's with ds_pk_add_bf16 (LDS atomic, two bf16 per instruction) instead of read - add - write
-#endif
-                        if (MSST_B4_PKADD && grp) {
-                            const s16x4 b4 = f2bf4(t4);
-                            const unsigned w0 = (unsigned)(unsigned short)b4[0] | ((unsigned)(unsigned short)b4[1] << 16);
-                            const unsigned w1_ = (unsigned)(unsigned short)b4[2] | ((unsigned)(unsigned short)b4[3] << 16);
-                            const unsigned la = (unsigned)(uintptr_t)(sm + o);
-                            asm volatile("ds_pk_add_bf16 %0, %1\n\tds_pk_add_bf16 %0, %2 offset:4" :: "v"(la), "v"(w0), "v"(w1_) : "memory");
-                            continue;
-                        }
-                        if (grp && !MSST_B4_ADDMFMA) {
-                            const s16x4 o4 = *reinterpret_cast<const lds_s16x4*>(sm + o);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) t4[e] += __builtin_bit_cast(float, (unsigned)(unsigned short)o4[e] << 16);
-                        }
                         lds_w64(sm, o, f2bf4(t4));
                     }
             }
             // the next tile's rows are in LDS.  The twelve phase-1 weight fragments requested above are this wave's twelve YOUNGEST memory
-            // operations (head A: rows at barrier B2, then the phase-4 weights, then load_w1; requests return in order), so vmcnt(12) covers
-            // the rows without sitting out the weights' L2 round trip in front of barrier B4 (MSST_B4_VMW = 0: wait for everything)
-#ifndef MSST_B4_VMW
-#define MSST_B4_VMW 0    // (12 measured 526.9 / 527.4 vs 526.9 / 531.2 us: nothing to gain, and the count is an invariant to maintain)
-#endif
-            if (!grp) { if (MSST_B4_VMW == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else wait_vm0(); }
+            // operations (head A: rows at barrier B2, then the phase-4 weights, then load_w1; requests return in order): vmcnt(12) would cover
+            // the rows without sitting out the weights' L2 round trip in front of barrier B4 -- measured: nothing to gain (526.9 / 527.4 vs 526.9 / 531.2 us), and the
+            // count would be an invariant to maintain; everything is waited for
+            if (!grp) wait_vm0();
         }
         R4_STAMP(7);
         bar3();   // B4
