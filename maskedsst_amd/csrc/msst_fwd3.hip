@@ -37,20 +37,11 @@
 #ifndef MSST_F3_RPRIO
 #define MSST_F3_RPRIO 1
 #endif
-#ifndef MSST_F3_PK
-#define MSST_F3_PK 0
-#endif
 #ifndef MSST_F3_BAND
 #define MSST_F3_BAND 1   // spectral blocks: skip the score tiles outside the band j - 1 .. j + 1 at compile time
 #endif
 #ifndef MSST_F3_GROUP
 #define MSST_F3_GROUP 10   // stack walk: a workgroup's tiles are cut into nmine / MSST_F3_GROUP groups; measured 3: +1.8 %, 6: -1.4 %, 10: -2.5 %, 100: -1.7 % (bench brackets, against per-block launches)
-#endif
-#ifndef MSST_F3_FWBASE
-#define MSST_F3_FWBASE 0   // 1: out-projection weight requests as scalar base + immediate offset (measured round 5: 287 vs 278 us -- SLOWER: the five scalar instructions per request sat in the shadow of the previous request's issue, and 24 back-to-back requests are not faster)
-#endif
-#ifndef MSST_F3_YSC1
-#define MSST_F3_YSC1 0   // 1: the block output rows leave with sc1 (write-through, the line is dropped from the XCD's L2): leaves the L2 to the x rows the residual add re-reads
 #endif
 #if defined(MSST_LAB) && !defined(MSST_LAB_X1OLD)
 #define MSST_LAB_X1OLD 0
@@ -526,29 +517,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                         for (int u = 0; u < 2; ++u) mc[u] = colgroup_max(mx[u]) * cs;
                         // exp(scale (s - max)) = exp2(s c - max c), c = scale log2 e: one FMA + one v_exp per element
-#if MSST_F3_PK
-                        // two scores per instruction where the ISA has a packed form (v_pk_fma_f32 for the exponent, v_pk_add_f32 for the
-                        // running sums): the A wave is bound by the number of instructions in its dependent chain, not by a pipe
-                        typedef float f32x2 __attribute__((ext_vector_type(2)));
-                        f32x2 sum2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int u = 0; u < 2; ++u) {
-                                if (!((NM[u] >> t) & 1u)) continue;
-                                const f32x2 cs2 = {cs, cs}, nm2 = {-mc[u], -mc[u]};
-#pragma unroll
-                                for (int r2 = 0; r2 < 2; ++r2) {
-                                    const f32x2 x2 = {s[u][t][2 * r2], s[u][t][2 * r2 + 1]};
-                                    const f32x2 a2 = __builtin_elementwise_fma(x2, cs2, nm2);
-                                    f32x2 e2 = {__builtin_amdgcn_exp2f(a2[0]), __builtin_amdgcn_exp2f(a2[1])};
-                                    s[u][t][2 * r2] = e2[0]; s[u][t][2 * r2 + 1] = e2[1];
-                                    sum2[u] = sum2[u] + e2;
-                                }
-                            }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) sum[u] = sum2[u][0] + sum2[u][1];
-#else
 #pragma unroll
                         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -557,7 +525,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(s[u][t][r], cs, -mc[u])); s[u][t][r] = e; sum[u] += e; }
                             }
-#endif
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const float st = colgroup_sum(sum[u]);
@@ -708,29 +675,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
     frag fw[8][3];
     auto request_fw = [&](int rd, int kstep) {
         const elem* wout = step_blk(kstep).wout;
-#if MSST_F3_FWBASE
-        // fragment (row tile 3 mh + i, k-step 8 rd + s8) of the packed [96][inner] matrix starts at byte 1024 ((3 mh + i) (inner / 32) + 8 rd + s8):
-        // six scalar bases per call (i x the two halves of s8) + the 12-bit offset field, instead of five scalar instructions
-        // per fragment (round 5: 24 fragments x 2 calls per tile were ~240 scalar instructions per R wave and tile, in q1 / q3 --
-        // the intervals in which the A waves wait for the R waves)
-        F3_LANE();
-        const int l16_ = l3 * 16, m_ = sopaque3(mh), kf = inner >> 5;
-        int base[3][2];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            base[i][0] = ((3 * m_ + i) * kf + 8 * rd) * 1024;
-            base[i][1] = base[i][0] + 4096;
-        }
-#pragma unroll
-        for (int s8 = 0; s8 < 8; ++s8)
-#pragma unroll
-            for (int i = 0; i < 3; ++i) fw[s8][i] = ld_wb3(wout, l16_ + (s8 & 3) * 1024, base[i][s8 >> 2]);
-#else
 #pragma unroll
         for (int s8 = 0; s8 < 8; ++s8)
 #pragma unroll
             for (int i = 0; i < 3; ++i) fw[s8][i] = P::ld_w(wout, inner, (3 * sopaque3(mh) + i) * 16, (8 * rd + s8) * 32);
-#endif
     };
     auto outproj = [&](int rd) {
         F3_LANE();
@@ -906,8 +854,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                     for (int r = 0; r < 4; ++r) o4[r] = yy[jj][jm][r] + lnp[480 + m0 + r];
                     if (DROP) o4 = drop4(drop_k, 4, (unsigned)(tok * 24 + (m0 >> 2)), o4);
                     o4 = o4 + x1r[jj][jm];
-                    if (MSST_F3_YSC1) asm volatile("global_store_dwordx4 %0, %1, off sc1" :: "v"(yp + tok * 96 + m0), "v"(o4) : "memory");
-                    else *reinterpret_cast<f32x4*>(yp + tok * 96 + m0) = o4;
+                    *reinterpret_cast<f32x4*>(yp + tok * 96 + m0) = o4;   // (with sc1 -- write-through, the line dropped from the XCD's L2, which leaves it to the x rows the residual add re-reads: 260.7 vs 255-259 us, no gain)
                 }
             }
         }
