@@ -333,6 +333,12 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
         for (int i = 0; i < MSST_B4_LAG; ++i) lds_barrier();   // head B: MSST_B4_LAG phases behind head A from here on
     }
 
+    s16x8 idf_h[2];   // head B: the two identity fragments of its phase-4 add, tile invariant (8 registers; rebuilt per tile they were 24 VALU instructions in front of head B's phase 4, the longest phase of the kernel's longest interval: -0.5 %)
+    {
+        const int t0_ = launder3(tid);
+#pragma unroll
+        for (int f2 = 0; f2 < 2; ++f2) idf_h[f2] = ident32_frag(f2, t0_ & 31, (t0_ >> 5) & 1);
+    }
     int xb = 0;   // row buffer of the tile
     int ks = 0;   // walk step
     for (int tile = QUEUE ? __builtin_amdgcn_readfirstlane(qt[0]) : (int)blockIdx.x; tile < a.ntiles;
@@ -781,7 +787,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         for (int f2 = 0; f2 < 2; ++f2)
                             fs[rt][f2] = lds_r128(sm, R4_OUT + (32 * rt + l31) * 192 + ((4 * wave + ((2 * f2 + hi) ^ fz2(l31))) << 4));
 #pragma unroll
-                    for (int f2 = 0; f2 < 2; ++f2) idf[f2] = ident32_frag(f2, l31, hi);
+                    for (int f2 = 0; f2 < 2; ++f2) idf[f2] = idf_h[f2];
 #pragma unroll
                     for (int f2 = 0; f2 < 2; ++f2) {
                         c4[0] = mma32(idf[f2], fs[0][f2], c4[0]);
