@@ -212,3 +212,32 @@ def test_stack_launch_refuses_operands_that_are_not_a_constant_stride_apart():
     acts, _ = eng.blocks_fwd(x0, save=False)
     assert torch.equal(buf[4], acts[1]) and torch.equal(buf[0], acts[3])
     assert torch.equal(ref, acts[3])
+
+
+@pytest.mark.parametrize("depth", [2, 12])
+def test_stack_forward_with_one_workgroup(depth, monkeypatch):
+    """MSST_MAX_GRID=1: ONE workgroup walks all 100 / 107 tiles of the B = 5 EnMAP shape.  depth 2: ten groups of ten tiles through two
+    blocks each (the many-groups walk, 200 / 220 steps).  depth 12: 1200 steps exceed the kernel's step table -- msst_block_fwd_stack
+    refuses (MSST_ERR_UNSUPPORTED) and the engine launches block by block.  Bit-identical to MSST_FWD_STACK=0 either way."""
+    monkeypatch.setenv("MSST_MAX_GRID", "1")
+    model, params, x = build_product(dict(bands=200, depth=depth, B=5), precision="bf16", device="cuda")
+    model.train()
+    eng = model.engine()
+    assert eng.max_grid == 1
+    eng.prep_weights()
+    x0 = eng.tokenize(x.cuda(), None)
+    drop = (0.1, 99)
+    calls = []
+    real = eng._fwd_stack
+    monkeypatch.setattr(eng, "_fwd_stack", lambda *a, **k: calls.append(real(*a, **k)) or calls[-1])
+    monkeypatch.setenv("MSST_FWD_STACK", "1")
+    a1, s1 = eng.blocks_fwd(x0, save=True, drop=drop)
+    torch.cuda.synchronize()
+    assert calls == ([True, True] if depth == 2 else [False, False])
+    monkeypatch.setenv("MSST_FWD_STACK", "0")
+    a0, s0 = eng.blocks_fwd(x0, save=True, drop=drop)
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(zip(a1, a0)):
+        assert torch.isfinite(p).all() and torch.equal(p, q), ("block output", i)
+    for i, (p, q) in enumerate(zip(s1, s0)):
+        assert torch.equal(p, q) and torch.equal(p._msst_xn, q._msst_xn) and torch.equal(p._msst_lse, q._msst_lse), ("saved rows", i)
