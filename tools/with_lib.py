@@ -8,4 +8,8 @@ lib, script = os.path.abspath(sys.argv[1]), sys.argv[2]
 sys.argv = sys.argv[2:]
 from maskedsst_amd import _lib
 _lib.LIB_PATH = lib
-runpy.run_path(script, run_name="__main__")
+if script == "-m":   # python tools/with_lib.py <lib> -m pytest tests/...
+    sys.argv = sys.argv[1:]
+    runpy.run_module(sys.argv[0], run_name="__main__", alter_sys=True)
+else:
+    runpy.run_path(script, run_name="__main__")
