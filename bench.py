@@ -86,6 +86,8 @@ def main():
                     help="backward persistent grids draw their tiles from a queue (what attach_data_parallel selects) instead of the static partition")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live HBM-traffic measurement (two short rocprofv3 --pmc child runs of this script: FETCH_SIZE, WRITE_SIZE)")
+    ap.add_argument("--no-probe", action="store_true",
+                    help="skip the box probe (msst_debug_box_probe: ~0.1 s before the warmup and after the timed region)")
     ap.add_argument("--force-dp", action="store_true",
                     help="single process, but through the data-parallel path: a one-rank RCCL process group, bucket hooks, "
                          "all-reduce calls, mean inside AdamW (MSST_FORCE_DP=1); for traces of the DP wiring on a 1-GPU box")
@@ -109,6 +111,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    ranks_seen = None
+    if dist.is_initialized():   # an all-reduce of ones: how many ranks RCCL really connected (the record of an N > 1 run carries its own proof)
+        one = torch.ones(1, device=dev, dtype=torch.float32)
+        dist.all_reduce(one)
+        ranks_seen = int(one.item())
 
     from maskedsst_amd import ViTSpatialSpectral, SimMIMSpatialSpectral, _lib
     from maskedsst_amd.optim import FusedAdamW, attach_data_parallel
@@ -130,6 +137,21 @@ def main():
 
     if args.tile_queue:
         model.engine().tile_queue = True
+    lib = _lib.load()
+
+    def box_probe():
+        """msst_debug_box_probe: what THIS box sustains right now (random-operand 32x32x16 bf16 MFMA stream, the shader clock it held,
+        a read-only HBM stream over 1 GiB); ~0.1 s, outside the timed region"""
+        scratch = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        out4 = (ctypes.c_double * 4)()
+        torch.cuda.synchronize()
+        _lib.check(lib.msst_debug_box_probe(out4, ctypes.c_void_p(scratch.data_ptr()), ctypes.c_long(scratch.numel()),
+                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "msst_debug_box_probe")
+        del scratch
+        return {"mfma_tflops_random": round(out4[0], 1), "clock_mhz": round(out4[1], 0), "hbm_read_gbps": round(out4[2], 0),
+                "seconds": round(out4[3], 3)}
+
+    probe_before = box_probe() if not args.no_probe else None
     B = args.batch
     g = torch.Generator(device="cpu").manual_seed(SEED + rank)
     img = torch.randn(B, args.bands, 8, 8, generator=g).to(dev)   # synthetic cubes, resident in HBM
@@ -153,7 +175,6 @@ def main():
         opt.step()
         return loss
 
-    lib = _lib.load()
     prof = not args.no_profile
     nk = lib.msst_profile_kernels()
 
@@ -210,6 +231,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     final_loss = float(loss.item())
+    probe_after = box_probe() if not args.no_probe else None
 
     # second timed region: the same step fed by the input pipeline (SyntheticCubeLoader: worker thread, pinned staging,
     # asynchronous host->device copies) instead of one resident batch -- reported next to `value`
@@ -261,6 +283,8 @@ def main():
             "final_loss": final_loss,
         }
         out["parity_note"] = parity_note(args.precision)
+        if ranks_seen is not None:
+            out["rccl_ranks_seen"] = ranks_seen
         if args.force_dp:
             out["forced_dp"] = True
         if args.cu_thief:
@@ -275,7 +299,11 @@ def main():
             cand = {k: v for k, v in kernels.items() if k in per}
             dom = max(cand, key=lambda k: cand[k]["total_ms"])
             ntok = B * S * N
-            fl = ntok * 0.5 * (per[dom](N) + per[dom](S))
+            # a stacked forward (msst_block_fwd_stack: the engine picks it for shapes whose workgroups hold few tiles) carries several
+            # blocks per launch: every per-launch figure of block_fwd (avg_us, bytes, FLOPs) then covers that many blocks
+            flb = getattr(model.engine(), "fwd_launch_blocks", None) or [1]
+            fwd_bpl = sum(flb) / len(flb)
+            fl = ntok * 0.5 * (per[dom](N) + per[dom](S)) * (fwd_bpl if dom == "block_fwd" else 1.0)
             avg_s = cand[dom]["avg_us"] * 1e-6
             achieved = fl / avg_s / 1e12
             # HBM bytes per launch of every kernel: measured live -- two short child runs of this script under rocprofv3 --pmc
@@ -299,23 +327,33 @@ def main():
                             break
                     except Exception:
                         continue
-            peak_measured, peak_file, pm = None, None, {}
-            hbm_measured = None
-            for pf in [os.path.basename(f) for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_peak_microbench.json")), reverse=True)]:
+            # what this box sustains: measured in THIS run by msst_debug_box_probe (before the warmup and after the timed region; the
+            # lower clock of the two is the one the timed region is priced against); the committed microbenchmark is the fallback
+            pm, peak_measured, hbm_measured, clock_mhz = {}, None, None, None
+            for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_peak_microbench.json")), reverse=True):
                 try:
-                    pm = json.load(open(os.path.join(ROOT, "profiles", pf)))
-                    peak_measured = pm.get("mfma_bf16_32x32x16_tflops") if args.precision == "bf16" else None
-                    hbm_measured = pm.get("hbm_copy_gbps")
-                    peak_file = pf
+                    pm = json.load(open(pf))
                     break
                 except Exception:
                     continue
+            if probe_before and probe_after:
+                pr = min(probe_before, probe_after, key=lambda d: d["mfma_tflops_random"])
+                peak_measured = pr["mfma_tflops_random"] if args.precision == "bf16" else None
+                clock_mhz, hbm_measured = pr["clock_mhz"], pr["hbm_read_gbps"]
+                peak_src = ("measured in this run: msst_debug_box_probe (back-to-back 32x32x16 bf16 MFMAs on hashed full-range operands, two "
+                            "waves per SIMD on every CU -- the chip clocks to its power budget; the lower of the probes before the warmup and "
+                            f"after the timed region, {pr['clock_mhz']:.0f} MHz against 2400 nominal)")
+                out["box_probe"] = {"before": probe_before, "after": probe_after}
+                # the same line on a box that holds 1900 MHz on the probe's stream (what the boxes of the pool differ by); an upper
+                # bound on what the clock explains: the HBM-bound ~20 % of the step does not follow the shader clock
+                out["value_at_1900mhz"] = round(value * 1900.0 / clock_mhz, 2) if clock_mhz else None
+            else:
+                peak_measured = pm.get("mfma_bf16_32x32x16_tflops") if args.precision == "bf16" else None
+                hbm_measured = pm.get("hbm_read_gbps_8_in_flight")
+                peak_src = "committed profiles/*_peak_microbench.json (tools/peak_microbench.hip on a box of this pool; NOT measured in this run: --no-probe)"
             out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": peak,
                                "peak_measured": peak_measured,
-                               "peak_measured_source": f"profiles/{peak_file} (tools/peak_microbench.hip on an MI355X of this pool: back-to-back "
-                                                       "32x32x16 bf16 MFMAs on hashed full-range operands -- the chip clocks to its power budget, "
-                                                       f"{pm.get('mfma_shader_clock_mhz_by_operands', {}).get('random', '?')} MHz on such data against 2400 nominal; "
-                                                       "committed, not measured in this run)",
+                               "peak_measured_source": peak_src,
                                "frac_of_measured_peak": round(achieved / peak_measured, 4) if peak_measured else None,
                                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                                "traffic_source": traffic_source,
@@ -324,6 +362,8 @@ def main():
             every = 1 if args.profile_all else max(1, args.profile_every)   # event pairs around every n-th launch only
             out["kernels"] = {k: {"avg_us": round(v["avg_us"], 2), "launches_timed": v["launches"], "timed_every": every,
                                   "share": round(min(1.0, every * v["total_ms"] / (1e3 * elapsed)), 4)} for k, v in kernels.items()}
+            out["blocks_per_launch"] = {"block_fwd": round(fwd_bpl, 2), "note": "every other kernel: one block (or one step) per launch; "
+                                        "block_fwd's avg_us / hbm_bytes_per_launch / algorithmic FLOPs cover this many blocks"}
             # HBM-bound kernels: GB/s = PMC bytes per launch (live passes above; else the committed table) / this run's average launch time
             try:
                 tj, tj_src = {}, None
@@ -344,8 +384,9 @@ def main():
                         if k in tj and k in times}
                     out["hbm_bound_kernels"]["bytes_source"] = tj_src
                     out["mfma_kernels_traffic"] = {k: {"hbm_bytes_per_launch": tj[k]["hbm_bytes_per_launch"]} for k in ("block_fwd", "block_bwd_attn") if k in tj}
-                    out["hbm_peak"] = {"nominal_gbps": 8000, "guide_achievable_gbps": 6290, "measured_copy_gbps": hbm_measured,
-                                       "measured_read_gbps": pm.get("hbm_read_gbps_8_in_flight"), "measured_write_gbps": pm.get("hbm_write_gbps")}
+                    out["hbm_peak"] = {"nominal_gbps": 8000, "guide_achievable_gbps": 6290, "measured_read_gbps_this_run": hbm_measured,
+                                       "committed_microbench": {"copy_gbps": pm.get("hbm_copy_gbps"), "read_gbps": pm.get("hbm_read_gbps_8_in_flight"),
+                                                                "write_gbps": pm.get("hbm_write_gbps")}}
             except Exception:
                 pass
             if survey and not args.profile_all:   # untimed warmup steps, every kernel bracketed
@@ -378,7 +419,19 @@ def pmc_pass(counter, child_args, outdir, limit):
     d = os.path.join(outdir, counter)
     cmd = [exe, "--pmc", counter, "--kernel-trace", "-f", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__)] + child_args
     env = dict(os.environ, TMPDIR="/tmp")
-    r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=limit)
+    # own session: on a timeout the WHOLE group goes (rocprofv3 and the python child it started), not just the profiler
+    import signal
+    proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        so, se = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        proc.communicate()
+        raise
+    r = subprocess.CompletedProcess(cmd, proc.returncode, so, se)
     vals = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
@@ -402,7 +455,7 @@ def measure_traffic(args):
     import tempfile
     child = ["--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--bands", str(args.bands), "--depth", str(args.depth),
              "--heads", str(args.heads), "--precision", args.precision, "--dropout", str(args.dropout),
-             "--no-cpu-baseline", "--no-profile", "--no-pipeline", "--no-traffic"] + (["--tile-queue"] if args.tile_queue else [])
+             "--no-cpu-baseline", "--no-profile", "--no-pipeline", "--no-traffic", "--no-probe"] + (["--tile-queue"] if args.tile_queue else [])
     out = tempfile.mkdtemp(prefix="msst_pmc_", dir="/tmp")
     t0 = time.perf_counter()
     try:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define MSST_VERSION 103
+#define MSST_VERSION 104
 #define MSST_DIM 96
 #define MSST_DIM_HEAD 64
 #define MSST_MLP 64
@@ -278,6 +278,12 @@ int msst_debug_stamps(void* device_buf /* >= 256 u64; kernel-study aid, see tool
  * enqueued on `stream`; sink: 4 bytes of device scratch.  Stands in for the channel workgroups of an RCCL collective when
  * the overlap of the gradient all-reduce with the backward is studied on ONE GPU. */
 int msst_debug_cu_thief(int nblocks, int microseconds, void* sink, void* stream);
+/* Box probe (diagnostic, bench.py `box_probe`; MSST_VERSION 104): what THIS GPU sustains right now -- out[0] = TFLOP/s of back-to-back
+ * v_mfma_f32_32x32x16_bf16 on hashed full-range operands (two waves per SIMD on every CU; the chip clocks to its power budget, so this
+ * differs from box to box and from the 2.5 PFLOP/s nominal), out[1] = the shader clock in MHz that stream held, out[2] = GB/s of a
+ * read-only stream over the scratch buffer, out[3] = seconds spent.  scratch: device memory, >= 1 MiB (>= 1 GiB for an HBM number:
+ * the memory-side cache holds 256 MB).  The one entry point that SYNCHRONISES the stream (it times with HIP events); <= 0.3 s. */
+int msst_debug_box_probe(double* out4, void* scratch, long scratch_bytes, void* stream);
 int msst_profile_enable(int on);
 /* restrict the event pairs to the kernel ids whose bit is set (default: all); each pair costs ~10 us of stream time */
 int msst_profile_select(unsigned long long mask);

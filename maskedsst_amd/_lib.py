@@ -72,6 +72,7 @@ _SIGS = {
                                   c_uint32, _P]),
     "msst_debug_stamps": (c_int, [_P]),
     "msst_debug_cu_thief": (c_int, [c_int, c_int, _P, _P]),
+    "msst_debug_box_probe": (c_int, [_P, _P, c_long, _P]),
     "msst_profile_enable": (c_int, [c_int]),
     "msst_profile_select": (c_int, [ctypes.c_ulonglong]),
     "msst_profile_sample": (c_int, [c_int]),

@@ -210,6 +210,10 @@ int msst_debug_cu_thief(int nblocks, int microseconds, void* sink, void* stream)
     return fail(launch_cu_thief(nblocks, microseconds, (unsigned*)sink, (hipStream_t)stream), "msst_debug_cu_thief");
 }
 
+int msst_debug_box_probe(double* out4, void* scratch, long scratch_bytes, void* stream) {
+    return fail(launch_box_probe(out4, scratch, scratch_bytes, (hipStream_t)stream), "msst_debug_box_probe");
+}
+
 int msst_profile_enable(int on) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     if (on) { g_prof.clear(); g_pool_next = 0; }
@@ -338,6 +342,7 @@ int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float
     a.stamps = nullptr;
     a.x1_bf16 = (dbg & 1024) ? 1 : 0;
     a.drop = make_drop(dropout_p, seed, layer0);
+    if (lse_out && !block_fwd_writes_lse(a, prec)) lse_out = nullptr;   // same rule as msst_block_fwd: a statistics buffer past the 31-bit descriptor range is declined, not clipped
     sa.nblk = nblk;
     // the kernel addresses block j's operands as block 0's + j x a byte stride: every array of the call must be affine in the block
     // index (maskedsst_amd lays its weight copies, parameters and activations out that way); anything else is refused
@@ -706,8 +711,13 @@ long msst_layernorm_bwd_slab(long rows, int D) { return rows < 1 || D < 1 ? 0 : 
 int msst_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta, float* slab,
                        long rows, int D, float eps, void* stream) {
     if (!dgamma || !dbeta) return fail(MSST_ERR_BADARG, "msst_layernorm_bwd");
-    if (rows == 0) return 0;
     hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {   // "fully written" holds for an empty input too: the sums over no rows
+        if (D < 1) return fail(MSST_ERR_BADARG, "msst_layernorm_bwd");
+        if (hipMemsetAsync(dgamma, 0, sizeof(float) * D, st) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * D, st) != hipSuccess)
+            return fail(MSST_ERR_BADARG, "msst_layernorm_bwd(memset)");
+        return 0;
+    }
     const int grid = layernorm_bwd_grid(rows, D);
     int rc = launch_layernorm_bwd(x, gamma, dy, dx, slab, grid, rows, D, eps, st);
     if (rc) return fail(rc, "msst_layernorm_bwd");

@@ -919,7 +919,9 @@ int launch_block_fwd(const BlockArgs& a, int prec, hipStream_t st) {
 }
 
 bool block_fwd_writes_lse(const BlockArgs& a, int prec) {
-    return prec == MSST_PREC_BF16 && a.H == 8 && !(a.dbg & (16 | 64));   // exactly the condition under which launch_block_fwd picks launch_block_fwd_rs
+    // exactly the condition under which launch_block_fwd picks launch_block_fwd_rs -- and a statistics buffer the 31-bit range of a
+    // buffer descriptor covers (the attention backward refuses a larger one, msst_bwd4.hip: the forward must not claim to have written it)
+    return prec == MSST_PREC_BF16 && a.H == 8 && !(a.dbg & (16 | 64)) && (long)a.ntiles * a.H * 256 < 0x7fffffffL;
 }
 
 bool block_fwd_writes_xn(const BlockArgs& a, int prec) {

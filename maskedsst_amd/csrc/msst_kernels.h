@@ -231,6 +231,7 @@ int launch_pos_split(const float* dpos, int S, int N, int split, float* dpe, flo
 int launch_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2, float eps,
                  float wd, int step, float clamp, float gscale, hipStream_t st);
 int launch_cu_thief(int nblocks, int us, unsigned* sink, hipStream_t st);   // msst_opt.hip (occupancy probe)
+int launch_box_probe(double* out4, void* scratch, long bytes, hipStream_t st);   // msst_opt.hip (MFMA rate / shader clock / HBM read rate of this box)
 int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st);   // msst_fwd3.hip (bf16, 8 heads; role split: the default)
 int launch_block_fwd_rs_stack(const StackArgs& a, int grid, hipStream_t st);   // the same for a run of blocks of one stack, ONE launch
 int block_fwd_stack_max_steps();

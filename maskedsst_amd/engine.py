@@ -268,14 +268,18 @@ class Engine:
         want_stack = os.environ.get("MSST_FWD_STACK", "auto")
         stacked = self.prec == PREC_BF16 and H == 8 and flags == 0 and want_stack != "0"
         i0 = 0
+        self.fwd_launch_blocks = []   # blocks carried by each block-forward launch of this call (bench.py normalises per-launch numbers with it)
         while i0 < len(layers):
             i1 = i0
             while i1 < len(layers) and layers[i1][0] == layers[i0][0] and i1 - i0 < 16:
                 i1 += 1
             use = stacked and (want_stack == "1" or self._tiles_per_workgroup(layers[i0][0], x0.shape[0]) <= STACK_MAX_TILES)
-            if not (use and self._fwd_stack(acts, x1s, i0, i1, save, drop, x1_bf16, want_lse)):
+            if use and self._fwd_stack(acts, x1s, i0, i1, save, drop, x1_bf16, want_lse):
+                self.fwd_launch_blocks.append(i1 - i0)
+            else:
                 for i in range(i0, i1):
                     self._fwd_block(acts, x1s, i, save, drop, x1_bf16, want_lse, flags)
+                self.fwd_launch_blocks += [1] * (i1 - i0)
             i0 = i1
         return acts, x1s
 

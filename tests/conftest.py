@@ -48,6 +48,19 @@ def oracle_cfg_from(cfg):
     )
 
 
+def apply_qkv_scale(named_tensors, cfg):
+    """The "peaky attention" fixtures (tools/make_golden.py::build, cfg key qkv_scale): every to_qkv.weight is multiplied by the
+    factor AFTER the seeded construction, in place."""
+    import torch
+    s = cfg.get("qkv_scale")
+    if not s:
+        return
+    with torch.no_grad():
+        for n, p in named_tensors:
+            if n.endswith("to_qkv.weight"):
+                p.mul_(float(s))
+
+
 def seed_all(seed=5):
     import random
     import torch

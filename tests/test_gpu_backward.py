@@ -1,4 +1,5 @@
 """GPU parity, backward: every parameter gradient of the HIP path vs autograd over the CPU oracle."""
+import numpy as np
 import pytest
 import torch
 
@@ -391,7 +392,9 @@ def test_bf16_x1_rows(cfg, monkeypatch):
 
 
 LSE_CASES = [dict(bands=200, depth=2, B=5), dict(bands=50, depth=2, B=4), dict(bands=30, depth=1, B=3, image_size=6, mask_patch_size=2),
-             dict(bands=200, depth=1, B=256)]
+             dict(bands=200, depth=1, B=256),
+             # round 6: peaky attention rows (to_qkv.weight x4: logit std ~5, max ~30, row maximum of p 0.5-0.8; tests/test_gpu_depth12.py)
+             dict(bands=200, depth=2, B=5, qkv_scale=4), dict(bands=50, depth=2, B=4, qkv_scale=4), dict(bands=50, depth=12, B=8, qkv_scale=4)]
 
 
 @pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 777)], ids=["nodrop", "drop0.1"])
@@ -402,7 +405,10 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     of its own max / sum / reciprocal (reference softmax: vit_spatial_spectral.py:71-73).
     (1) the saved values against a torch restatement from the saved LN1 rows and the bf16 weights the kernels used;
     (2) the backward with the saved statistics against the backward that normalises by itself (MSST_LSE=0) on the same rows
-        and masks: same rounding points for q / k / v, p differs by the fp32 summation order of the two kernels' scores."""
+        and masks: same rounding points for q / k / v, p differs by the fp32 summation order of the two kernels' scores;
+    (3) round 6: BOTH backwards against the oracle's autograd through the same blocks (same tokens in, same dy, the kernels' dropout
+        masks) -- with saved statistics the rows of p no longer sum to 1 by construction, so the question is whether the lse path
+        sits further from the exact gradient than the self-normalising one, in particular on peaky rows (qkv_scale cases)."""
     model, params, x = build_product(cfg, precision="bf16", device="cuda")
     eng = model.engine()
     masks = model.draw_masks(cfg["B"])
@@ -415,6 +421,7 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
         eng.fp.grad.zero_()
         dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy, drop=drop)
         torch.cuda.synchronize()
+        run.dy = dy
         return out, dx0.clone(), eng.fp.grad.clone()
 
     o1, dx1, g1 = run("1")
@@ -437,7 +444,8 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     ntiles = (nseq + TS - 1) // TS
     got = lse.reshape(ntiles, H, 64)[:, :, :TS * N].reshape(ntiles, H, TS, N).permute(0, 2, 1, 3).reshape(ntiles * TS, H, N)[:nseq]
     err = float((got - ref).abs().max())
-    assert err < 2e-2, err      # bf16 q / k (three significant digits) in scores of magnitude ~1: measured ~4e-3
+    # bf16 q / k (three significant digits) in scores of magnitude ~1: measured ~4e-3; the scores of the peaky cases are 16x larger
+    assert err < 2e-2 * float(cfg.get("qkv_scale", 1)) ** 2, err
     # (2)
     e_dx = rel_l2(dx1, dx0)
     worst, bad = 0.0, []
@@ -449,9 +457,32 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
         worst = max(worst, e)
         if not e < 6.3e-3:
             bad.append((name, e))
-    record("saved_softmax_statistics", cfg=cfg, drop=list(drop), lse_abs_err=err, dx=e_dx, worst_grad=worst)
-    assert e_dx < 1.5e-3, e_dx
-    assert not bad, bad
+    # (3) the oracle's autograd through the same blocks
+    from oracle import transformer_forward
+    from dropout import make_drop_fn
+    ocfg = oracle_cfg_from(cfg)
+    blk = {k: v.clone().requires_grad_(True) for k, v in params.items() if ".layers." in k}
+    tok = o1["tok_masked"].detach().float().cpu().requires_grad_(True)
+    y = transformer_forward(blk, tok, ocfg, drop_fn=make_drop_fn(drop[0], drop[1], ocfg.S, ocfg.N, ocfg.heads) if drop[0] else None)
+    y.backward(run.dy.cpu())
+    flat = {id(q): n for n, q in eng.trainable()}
+    vs_oracle = {}
+    for tag, dxk, gk in (("lse", dx1, g1), ("own", dx0, g0)):
+        ge = {pn: rel_l2(eng.fp.view(flat[id(q)], gk), blk[pn].grad) for pn, q in model.named_parameters() if pn in blk}
+        vs_oracle[tag] = dict(dx=rel_l2(dxk, tok.grad), worst_grad=max(ge.values()), median_grad=float(np.median(list(ge.values()))))
+    peaky = "qkv_scale" in cfg
+    record("saved_softmax_statistics", cfg=cfg, drop=list(drop), lse_abs_err=err, dx=e_dx, worst_grad=worst,
+           oracle_lse_dx=vs_oracle["lse"]["dx"], oracle_own_dx=vs_oracle["own"]["dx"],
+           oracle_lse_worst_grad=vs_oracle["lse"]["worst_grad"], oracle_own_worst_grad=vs_oracle["own"]["worst_grad"])
+    # the lse path may not sit further from the exact gradient than the self-normalising one (10 % slack for rounding luck)
+    assert vs_oracle["lse"]["dx"] < 1.1 * vs_oracle["own"]["dx"] + 1e-4, vs_oracle
+    assert vs_oracle["lse"]["worst_grad"] < 1.1 * vs_oracle["own"]["worst_grad"] + 1e-4, vs_oracle
+    if not peaky:
+        assert e_dx < 1.5e-3, e_dx
+        assert not bad, bad
+    else:                       # PLACEHOLDER bars until measured on the device
+        assert e_dx < 0.2, e_dx
+        assert worst < 0.2, (worst, bad[:3])
 
 
 def test_bf16_x1_rows_with_a_large_row_offset(monkeypatch):

@@ -20,6 +20,14 @@ from util import build_product, relerr, rel_l2, record
 pytestmark = pytest.mark.gpu
 
 L12 = ["simmim_200b_L12_B4.npz", "simmim_50b_L12_B8.npz", "simmim_50b_L12_B8_zeropad.npz"]
+# Round 6: the same two shapes with PEAKY attention rows -- every to_qkv.weight x4 after construction, built by the
+# reference's own modules (tools/make_golden.py peaky).  Logit std ~5, max |logit| 25-34, mean row maximum of the softmax 0.5-0.8 (the
+# fixtures carry the measured `attn_stats`): the regime a trained model lives in, where a softmax / scale error moves every stage.
+# (The scores go with the SQUARE of the factor.  x8 -- logit std 22, rows 0.9 one-hot -- and x16 are past what fp32 can pin: the
+# reference and the oracle, two fp32 CPU evaluations of the same formulas, already differ by 8e-2 of max in enc_out and 0.6 in a
+# gradient tensor at x8, and by 4e-3 ... 8e-3 in the LOSS at x16; test_peaky_x8_conditioning below keeps x8 as a robustness case.)
+PEAKY = ["simmim_200b_L12_B4_qkv4.npz", "simmim_50b_L12_B8_qkv4.npz"]
+PEAKY8 = ["simmim_200b_L12_B4_qkv8.npz", "simmim_50b_L12_B8_qkv8.npz"]
 STAGES = ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred"]
 
 
@@ -39,7 +47,7 @@ def check_masks_against_fixture(masks, g):
     np.testing.assert_array_equal(masks[1].numpy().astype(np.int16), g["masked_indices"])
 
 
-@pytest.mark.parametrize("name", L12)
+@pytest.mark.parametrize("name", L12 + PEAKY)
 def test_depth12_fp32_vs_fixture_and_oracle(name):
     """fp32 MFMA mode, 24 blocks: the reference's own numbers (fixture) and the oracle's full tensors."""
     g = load_golden(name)
@@ -93,10 +101,14 @@ BF16_BARS = {
     "simmim_200b_L12_B4.npz": dict(loss=2.8e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
     "simmim_50b_L12_B8.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
     "simmim_50b_L12_B8_zeropad.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
+    # peaky rows: a bf16 q / k pair (2^-9 relative each) moves a logit of 30 by ~0.06, i.e. a probability by 6 %: the bf16 noise of
+    # these cases is an order of magnitude above the uniform-attention cases' by construction (PLACEHOLDER bars until measured)
+    "simmim_200b_L12_B4_qkv4.npz": dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5, cos=0.9),
+    "simmim_50b_L12_B8_qkv4.npz": dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5, cos=0.9),
 }
 
 
-@pytest.mark.parametrize("name", L12)
+@pytest.mark.parametrize("name", L12 + PEAKY)
 def test_depth12_bf16_vs_oracle(name):
     """The benchmarked bf16 kernels through 24 blocks: loss vs the reference anchor, every stage vs the oracle, and --
     with the oracle's sign pattern fed to the backward (the L1 gradient is sign(pred - target); bf16 rounding flips
@@ -152,6 +164,41 @@ def test_depth12_bf16_vs_oracle(name):
     assert cos > bars["cos"], cos
     assert dx0_err < bars["dx0"], dx0_err
     assert gerr[worst_name] < bars["grad"], (worst_name, gerr[worst_name])
+
+
+@pytest.mark.parametrize("name", PEAKY8)
+def test_peaky_x8_conditioning(name):
+    """to_qkv.weight x8: logit std ~22, max |logit| 100-130, softmax rows 0.9 one-hot -- past the point where fp32 pins anything
+    element-wise (the reference and the oracle differ by 8e-2 of max in enc_out on the CPU; tests/test_oracle_golden.py holds those
+    numbers).  What is still well defined is checked: masks bit-exact, the fp32-mode loss against the reference's to 1e-3 (reference vs
+    oracle: 2e-5 / 1.2e-4), every stage finite and no further from the oracle than the oracle is from the reference (x4 margin), and
+    the bf16 kernels -- exp2 of scores up to 130 * log2 e, saved lse included -- finite with a loss within 5 %."""
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, params, x = build_product(cfg, precision="fp32", device="cuda")
+    masks = model.draw_masks(cfg["B"])
+    check_masks_against_fixture(masks, g)
+    eng = model.engine()
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    torch.cuda.synchronize()
+    lf = float(g["loss"])
+    loss_err = abs(out["loss"].item() - lf) / lf
+    from oracle import simmim_forward
+    with torch.no_grad():
+        ref = simmim_forward(params, x, oracle_cfg_from(cfg), masks=masks)
+    stage_err = {k: relerr(out[k], ref[k]) for k in STAGES}
+    eng.set_precision("bf16")
+    model.zero_grad(set_to_none=True)
+    loss = model(x.cuda(), masks=masks)
+    loss.backward()
+    torch.cuda.synchronize()
+    bf16_loss_err = abs(loss.item() - lf) / lf
+    finite = all(torch.isfinite(p.grad).all().item() for p in model.parameters() if p.grad is not None)
+    record("peaky_x8_conditioning", fixture=name, loss_err=loss_err, stage_err=stage_err, bf16_loss_err=bf16_loss_err)
+    assert loss_err < 1e-3, loss_err
+    assert all(torch.isfinite(out[k]).all() for k in STAGES)
+    assert max(stage_err.values()) < 0.4, stage_err
+    assert finite and bf16_loss_err < 5e-2, bf16_loss_err
 
 
 def test_full_size_b256_bf16():

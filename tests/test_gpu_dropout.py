@@ -57,15 +57,20 @@ def test_dropout_fwd_bwd_fp32_same_masks(cfg):
 # bars 3-4x measured on MI355X (profiles/r0N_parity_measured.jsonl): loss 2.0e-4, enc_out 3.1e-3 max-norm, dx0 3.0e-3 rel-L2,
 # worst parameter-gradient tensor 5.2e-3 rel-L2 (median 2.7e-3)
 BF16_DROP_BARS = dict(loss=7e-4, stage=1.1e-2, dx0=1.05e-2, grad=1.8e-2)
+# peaky attention rows (to_qkv.weight x4, tests/test_gpu_depth12.py): PLACEHOLDER bars until measured on the device
+BF16_DROP_BARS_PEAKY = dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5)
 
 
-def test_dropout_bf16_depth12_same_masks():
+@pytest.mark.parametrize("qkv_scale", [None, 4], ids=["init", "peaky-x4"])
+def test_dropout_bf16_depth12_same_masks(qkv_scale):
     """The configuration bench.py times -- bf16 kernels, dropout 0.1, depth 12 (24 blocks) -- against the oracle run with
     EXACTLY the kernels' masks (Houston shape, B = 8): loss, encoder output, and with the oracle's L1 sign pattern fed to
     the backward, dx0 and every parameter gradient."""
     from oracle import simmim_forward
     from maskedsst_amd.masking import inverse_csr
     cfg = dict(bands=50, depth=12, B=8)
+    if qkv_scale:
+        cfg["qkv_scale"] = qkv_scale
     p, seed = 0.1, 424243
     model, params, x = build_product(cfg, precision="bf16", device="cuda")
     ocfg = oracle_cfg_from(cfg)
@@ -97,8 +102,8 @@ def test_dropout_bf16_depth12_same_masks():
         gerr[name] = rel_l2(eng.fp.view(flat[id(q)], eng.fp.grad), g_ref)
     worst = max(gerr, key=gerr.get)
     record("dropout_bf16_depth12", loss_err=loss_err, enc_out_err=stage_err, dx0_err=dx0_err, worst_grad=gerr[worst],
-           worst_grad_name=worst, median_grad=float(np.median(list(gerr.values()))))
-    b = BF16_DROP_BARS
+           worst_grad_name=worst, median_grad=float(np.median(list(gerr.values()))), **({"qkv_scale": qkv_scale} if qkv_scale else {}))
+    b = BF16_DROP_BARS_PEAKY if qkv_scale else BF16_DROP_BARS
     assert loss_err < b["loss"], loss_err
     assert stage_err < b["stage"], stage_err
     assert dx0_err < b["dx0"], dx0_err

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, load_golden, fp_np, oracle_cfg_from, seed_all
+from conftest import GOLDEN, load_golden, fp_np, oracle_cfg_from, seed_all, apply_qkv_scale
 from oracle import init_params, simmim_forward, classify_forward
 
 SIMMIM = sorted(os.path.basename(p) for p in glob.glob(os.path.join(GOLDEN, "simmim_*.npz")))
@@ -23,6 +23,7 @@ def run_oracle(g):
     cfg = oracle_cfg_from(g["cfg"])
     seed_all(5)
     params = init_params(cfg)
+    apply_qkv_scale(params.items(), g["cfg"])
     B = g["cfg"]["B"]
     x = torch.randn(B, cfg.bands, cfg.image_size, cfg.image_size)
     if g["cfg"].get("zero_pad_bands"):
@@ -44,10 +45,20 @@ def check_fp(a, b, rtol, atol, what):
     np.testing.assert_allclose(a[3:], b[3:], rtol=max(rtol, 1e-5) * 10, atol=atol * 10, err_msg=what)
 
 
+def conditioning(gcfg):
+    """How far two fp32 evaluations of the SAME formulas may sit apart on a fixture: 1 for the randomly initialised models.  The
+    peaky-attention fixtures (to_qkv.weight x s, logits x s^2) amplify fp32 round-off through 24 blocks; measured oracle vs reference
+    on the CPU -- x4: stages 1.3e-5 of max, gradients 2.6e-5 (still pinned at the ordinary bars, slices relative to the tensor's
+    max); x8: loss 2e-5 / 1.2e-4, enc_out 8e-2 of max, a gradient tensor's abs-sum 0.6: only the loss, the masks and the
+    parameters are held (tests/test_gpu_depth12.py::test_peaky_x8_conditioning says what that fixture is for)."""
+    return {None: "exact", 4: "exact", 8: "loss-only"}[gcfg.get("qkv_scale")]
+
+
 @pytest.mark.parametrize("name", FAST + SLOW)
 def test_simmim_matches_reference(name):
     g = load_golden(name)
     cfg, params, x, out = run_oracle(g)
+    cond = conditioning(g["cfg"])
     # input + parameter draw order: bit-exact
     np.testing.assert_array_equal(fp_np(x), g["x_fp"])
     assert list(params.keys()) == g["names"] or sorted(params.keys()) == sorted(g["names"])
@@ -59,12 +70,18 @@ def test_simmim_matches_reference(name):
     np.testing.assert_array_equal(bits, g["bool_mask_bits"])
     np.testing.assert_array_equal(out["masked_indices"].numpy().astype(np.int16), g["masked_indices"])
     # loss + intermediates
+    if cond == "loss-only":
+        assert abs(out["loss"].item() - float(g["loss"])) <= 5e-4 * abs(float(g["loss"]))
+        for k in ["tok_embed", "tok_masked", "target"]:      # everything in front of the first attention block is still exact
+            check_fp(fp_np(out[k]), g["i_fp/" + k], 1e-5, 2e-6, k)
+        return
     assert abs(out["loss"].item() - float(g["loss"])) <= 2e-6 * abs(float(g["loss"])) + 1e-10
     for k in ["tok_embed", "tok_masked", "after_spatial", "enc_out", "pred", "target"]:
         check_fp(fp_np(out[k]), g["i_fp/" + k], 1e-5, 2e-6, k)
         flat = out[k].detach().reshape(-1)
         stride = max(1, flat.numel() // 64)
-        np.testing.assert_allclose(flat[::stride][:64].numpy(), g["i_slice/" + k], rtol=2e-4, atol=2e-5, err_msg=k)
+        want = g["i_slice/" + k]
+        np.testing.assert_allclose(flat[::stride][:64].numpy(), want, rtol=2e-4, atol=2e-5 * max(1.0, float(np.abs(want).max())), err_msg=k)
     # gradients
     gsq = 0.0
     for k, p in params.items():
@@ -79,6 +96,8 @@ def test_simmim_matches_reference(name):
         np.testing.assert_allclose(got[3:], ref[3:], rtol=5e-3, atol=50 * scale * 1e-3, err_msg=k)
         gsq += float((p.grad.double() ** 2).sum())
     assert abs(gsq ** 0.5 - float(g["grad_l2"])) <= 1e-4 * float(g["grad_l2"])
+    if "attn_stats" in g:       # the fixture really is peaky: mean row maximum of the softmax >= 0.5 in every sampled block
+        assert g["attn_stats"][:, 2].min() >= 0.5 and g["attn_stats"][:, 0].min() > 4.0, g["attn_stats"]
 
 
 @pytest.mark.parametrize("name", [n for n in SIMMIM if "tiny" in n])
