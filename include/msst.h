@@ -42,6 +42,11 @@ extern "C" {
                                             8 heads, no MSST_KERNEL_* flag; MSST_ERR_UNSUPPORTED otherwise), msst_block_bwd / _chain read x1 and x1_prev so (bf16
                                             kernels only).  A quarter of the forward's writes and 8 % of the fused row-local backward's reads less; the LN2 statistics
                                             of the backward are then those of the rounded rows (parity: tests/test_gpu_backward.py::test_bf16_x1_rows) */
+#define MSST_LN1_FROM_XN (2048 << 8)      /* msst_block_bwd_chain (MSST_VERSION 104): the fused LN1 + MLP launch takes xhat of LN1 from the saved bf16 LN1 rows and
+                                            the saved rstd -- xhat = (xn_saved - ln1_b) / ln1_g, rstd = the tail of lse_saved (MSST_SAVED_RSTD) -- instead of
+                                            re-reading and re-normalising the fp32 block input x: 192 bytes per token less of 2304.  The caller sets it only when
+                                            every ln1_g is safely away from 0 and |ln1_b / ln1_g| is moderate (the division amplifies the rows' bf16 rounding by
+                                            1 + |b / g| / |xhat|; maskedsst_amd/engine.py: max |b / g| <= 12); needs xn_saved and lse_saved */
 #define MSST_BWD_DEFER_REDUCE (512 << 8) /* msst_block_bwd_chain: leave the partial-gradient slabs of this call unreduced (msst_block_bwd_reduce does a run of calls in one launch) */
 #define MSST_KERNEL_ATTN_R3 (128 << 8)   /* bf16 attention backward: one head per workgroup (msst_bwd3.hip) instead of two (msst_bwd4.hip) */
 
@@ -115,16 +120,23 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
  * mask keyed by (seed, layer, site, element); msst_block_bwd regenerates it from the same three values.
  * xn_out (optional, [tokens][96] bf16): receives LN1(x) exactly as the block used it, so that msst_block_bwd neither
  * re-reads x nor renormalises it.
- * lse_out (optional, msst_block_lse_floats(...) fp32): receives, per (64-row tile, head, row), lse = log2 of the row's softmax
- * denominator in the exponent domain of the kernels (p = exp2(s * dim_head^-0.5 * log2 e - lse), vit_spatial_spectral.py:71-73):
- * the attention backward then computes the probabilities directly -- no row maximum, no row sum, no reciprocal.  10-11 MB per
- * block at the bench shape; the tile order is the forward's own (same mode / shapes on both sides).
- * *saved (host, optional) tells which of the two the selected kernel wrote: MSST_SAVED_XN (the two tuned bf16 kernels -- role
- * split for 8 heads, 4-wave otherwise; not fp32, not MSST_KERNEL_GENERIC), MSST_SAVED_LSE (the role-split kernel only).  Pass
- * xn_saved / lse_saved to msst_block_bwd only when the bit is set. */
+ * lse_out (optional, msst_block_lse_floats(...) fp32): the block's saved STATISTICS, two arrays back to back --
+ *   [msst_block_tiles(...)][heads][64]: per (64-row tile, head, row), lse = log2 of the row's softmax denominator in the exponent
+ *     domain of the kernels (p = exp2(s * dim_head^-0.5 * log2 e - lse), vit_spatial_spectral.py:71-73): the attention backward
+ *     then computes the probabilities directly -- no row maximum, no row sum, no reciprocal; the tile order is the forward's own
+ *     (same mode / shapes on both sides);
+ *   [tokens] (MSST_VERSION 104): rstd of LN1 of every token (vit_spatial_spectral.py:22-29), token order: with it and the bf16 LN1
+ *     rows (xn_out) the fused row-local backward rebuilds xhat = (LN1 row - beta) / gamma and does not read the fp32 block input
+ *     at all (MSST_LN1_FROM_XN).
+ *   10-12 MB per block at the bench shape.
+ * *saved (host, optional) tells which of them the selected kernel wrote: MSST_SAVED_XN (the two tuned bf16 kernels -- role
+ * split for 8 heads, 4-wave otherwise; not fp32, not MSST_KERNEL_GENERIC), MSST_SAVED_LSE and MSST_SAVED_RSTD (the role-split
+ * kernel only).  Pass xn_saved / lse_saved to msst_block_bwd only when the bit is set. */
 #define MSST_SAVED_XN 1
 #define MSST_SAVED_LSE 2
-long msst_block_lse_floats(int mode, int B, int S, int N, int heads);
+#define MSST_SAVED_RSTD 4
+long msst_block_lse_floats(int mode, int B, int S, int N, int heads);   /* floats of the whole statistics buffer: tiles * heads * 64 + tokens */
+long msst_block_tiles(int mode, int B, int S, int N);                   /* 64-row tiles of a block launch (the forward's own tiling) */
 int msst_block_fwd(const MsstBlockWeights* w /*host*/, const float* x, float* y, float* x1, int mode,
                    int B, int S, int N, int heads, int prec, int max_grid, float dropout_p, uint32_t seed,
                    int layer, void* xn_out, float* lse_out, int* saved /*host*/, void* stream);

@@ -43,7 +43,8 @@ class MsstBlockGrads(Structure):
 _P = c_void_p
 BWD_DEFER_REDUCE = 512 << 8   # include/msst.h: MSST_BWD_DEFER_REDUCE
 X1_BF16 = 1024 << 8           # include/msst.h: MSST_X1_BF16
-SAVED_XN, SAVED_LSE = 1, 2    # include/msst.h: MSST_SAVED_*
+SAVED_XN, SAVED_LSE, SAVED_RSTD = 1, 2, 4    # include/msst.h: MSST_SAVED_*
+LN1_FROM_XN = 2048 << 8       # include/msst.h: MSST_LN1_FROM_XN
 _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),
@@ -52,6 +53,7 @@ _SIGS = {
     "msst_cls_head_fwd": (c_int, [_P] * 6 + [c_int, c_int, c_int, c_int, _P]),
     "msst_cls_head_bwd": (c_int, [_P] * 11 + [c_int, c_int, c_int, c_int, _P]),
     "msst_block_lse_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+    "msst_block_tiles": (c_long, [c_int, c_int, c_int, c_int]),
     "msst_block_fwd": (c_int, [POINTER(MsstBlockWeights), _P, _P, _P, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_int, c_float, c_uint32, c_int, _P, _P, POINTER(c_int), _P]),
     "msst_block_fwd_stack": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_uint32, c_int,

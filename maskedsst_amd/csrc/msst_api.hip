@@ -283,7 +283,12 @@ int msst_tokenize_fwd(const float* img, const float* pre_g, const float* pre_b, 
 
 long msst_block_lse_floats(int mode, int B, int S, int N, int heads) {
     if (B < 1 || S < 1 || N < 1 || heads < 1 || N > 64 || S > 64) return 0;
-    return (long)ntiles_of(make_tilemap(mode, B, S, N)) * heads * 64;
+    return (long)ntiles_of(make_tilemap(mode, B, S, N)) * heads * 64 + (long)B * S * N;   // [tiles][heads][64] lse | [tokens] rstd of LN1
+}
+
+long msst_block_tiles(int mode, int B, int S, int N) {
+    if (B < 1 || S < 1 || N < 1 || N > 64 || S > 64) return 0;
+    return (long)ntiles_of(make_tilemap(mode, B, S, N));
 }
 
 int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x1, int mode, int B, int S,
@@ -316,7 +321,7 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.drop = make_drop(dropout_p, seed, layer);
     a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
     a.lse_out = (lse_out && block_fwd_writes_lse(a, prec)) ? lse_out : nullptr;
-    if (saved) *saved = (a.xn_out ? MSST_SAVED_XN : 0) | (a.lse_out ? MSST_SAVED_LSE : 0);
+    if (saved) *saved = (a.xn_out ? MSST_SAVED_XN : 0) | (a.lse_out ? (MSST_SAVED_LSE | MSST_SAVED_RSTD) : 0);
     return fail(launch_block_fwd(a, prec, (hipStream_t)stream), "msst_block_fwd");
 }
 
@@ -388,7 +393,7 @@ int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float
     }
     if (!affine) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (per-block operands not a constant stride apart)");
     sa.x_rest = nblk > 1 ? reinterpret_cast<const float*>(reinterpret_cast<const char*>(y[0]) - (long)sa.st.y) : x0;   // x of block j >= 1 = x_rest + j stride_y
-    if (saved) *saved = (xn_out ? MSST_SAVED_XN : 0) | (lse_out ? MSST_SAVED_LSE : 0);
+    if (saved) *saved = (xn_out ? MSST_SAVED_XN : 0) | (lse_out ? (MSST_SAVED_LSE | MSST_SAVED_RSTD) : 0);
     if (a.ntiles < 1) return 0;
     int ncu = 256, dev = 0;
     hipGetDevice(&dev);
@@ -574,6 +579,12 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         LnMlpArgs a;
         a.w = to_bw(w_prev); a.ln1_g = w->ln1_g; a.x = x; a.dx1 = dx1; a.dxn_part = dxn_part; a.x1 = x1_prev; a.dab = dab_ws;
         a.x1_bf16 = x1b;
+        // MSST_LN1_FROM_XN: xhat of LN1 from the saved bf16 LN1 rows + the saved rstd (the tail of the statistics buffer)
+        a.xn = nullptr; a.rstd = nullptr; a.ln1_b = w->ln1_b;
+        if (dbg & 2048) {
+            if (!xn_saved || !lse_saved) return fail(MSST_ERR_BADARG, "msst_block_bwd_chain (MSST_LN1_FROM_XN needs xn_saved and lse_saved)");
+            a.xn = xn_saved; a.rstd = lse_saved + (long)aa.ntiles * heads * 64;
+        }
         a.slab_mlp = slab_mlp_prev; a.slab_ln1 = slab_ln1; a.ntok = ntok; a.nparts = nparts;
         a.drop_i = drop; a.drop_p = make_drop(dropout_p, seed, layer - 1);
         a.stamps = nullptr;

@@ -64,6 +64,8 @@ struct LmSmem {
     float dxf[2][64][LDF];   // dx_i (fp32) of the tile the M waves process now / next, by walk-step parity
     float out[64][LDF];      // dx1 of block i - 1 (fp32) of the tile the M waves just finished: the L waves copy it out as whole rows
     float gam1[96];          // ln1_g of block i
+    float bet1[96];          // (XNB) ln1_b / ln1_g of block i
+    float ig1[96];           // (XNB) 1 / ln1_g
     int qt[8];               // (QUEUE) tile of walk step k at [k & 7]
     float lnp[256];          // ln2_g | ln2_b | b1 of block i - 1
     char wl[36 * 1024];      // [w1 12 | w2T 12 | w1T 12] fragments of 1 KB (block i - 1)
@@ -81,7 +83,9 @@ __device__ __forceinline__ float oct_sum5(float v) {
 // QUEUE (data parallel, opt-in): tiles drawn from one agent-scope counter instead of the static partition tile = workgroup +
 // k grid, so that a workgroup whose CU is held by a communication kernel draws fewer tiles instead of running its whole share
 // behind the others (see msst_bwd4.hip).  L wave 0 draws five walk steps ahead and publishes through an eight-entry LDS ring.
-template <int NP, bool DROP, bool QUEUE, bool X1B>
+// XNB (MSST_LN1_FROM_XN, round 6): xhat of LN1 = (saved bf16 LN1 row - beta) / gamma and rstd from the forward's statistics buffer
+// instead of the fp32 block input x re-read and re-normalised: 196 instead of 384 bytes per row, no mean / variance reductions.
+template <int NP, bool DROP, bool QUEUE, bool X1B, bool XNB>
 __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
     typedef LmSmem SM;
     constexpr int KS = 32, LDX = SM::LDX, LDH = SM::LDH;
@@ -109,7 +113,11 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
 
     // ---- common prologue: block i - 1's small vectors and the three MLP weight matrices -> LDS ----
     if (tid < 96) { sm.lnp[tid] = a.w.ln2_g[tid]; sm.lnp[96 + tid] = a.w.ln2_b[tid]; if (tid < 64) sm.lnp[192 + tid] = a.w.b1[tid]; }
-    if (tid >= 256 && tid < 352) sm.gam1[tid - 256] = a.ln1_g[tid - 256];
+    if (tid >= 256 && tid < 352) {
+        const float g_ = a.ln1_g[tid - 256];
+        sm.gam1[tid - 256] = g_;
+        if (XNB) { const float ig_ = 1.0f / g_; sm.ig1[tid - 256] = ig_; sm.bet1[tid - 256] = a.ln1_b[tid - 256] * ig_; }   // (bet1: beta / gamma)
+    }
     {
         const elem* w1 = reinterpret_cast<const elem*>(a.w.w1);
         const elem* w1T = reinterpret_cast<const elem*>(a.w.w1T);
@@ -139,11 +147,15 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
 #pragma unroll
         for (int i = 0; i < 12; ++i) { dg[i] = 0.f; db[i] = 0.f; dbo[i] = 0.f; }
         f32x4 xq[2][3], dq[2][3];
+        u32x4 xna[2];   // (XNB, instead of xq) bf16 LN1 row: features 8 p .. 8 p + 7,
+        u32x2 xnb[2];   //   features 64 + 4 p .. + 3,
+        float xrs[2];   //   the row's rstd
         u32x4 pa[2][NP];
         u32x2 pb[2][NP];
         // buffer loads: descriptors in SGPRs, four 32-bit lane offsets per pass (64-bit address pairs per request cost registers the
         // whole-tile prefetch does not have)
-        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(XNB ? const_cast<void*>(a.xn) : (void*)const_cast<float*>(a.x), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.rstd), 0, XNB ? 0x7fffffff : 0, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.dx1, 0, 0x7fffffff, 0x00020000);
         const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(const_cast<elem*>(parts), 0, 0x7fffffff, 0x00020000);
         const int pstride = (int)(a.ntok * 192);   // bytes between partial buffers (launcher: nparts * ntok * 192 < 2^31)
@@ -157,9 +169,15 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
                 const int tokc = (tok < (int)a.ntok && live) ? tok : 0;
                 const int vo1 = tokc * 384 + 32 * p, vo2 = tokc * 384 + 256 + 16 * p;
                 const int vp1 = tokc * 192 + 16 * p, vp2 = tokc * 192 + 128 + 8 * p;
-                xq[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo1, 0, 0));
-                xq[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo1 + 16, 0, 0));
-                xq[ps][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo2, 0, 0));
+                if constexpr (XNB) {
+                    xna[ps] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, vp1, 0, 0);
+                    xnb[ps] = __builtin_amdgcn_raw_buffer_load_b64(rs_x, vp2, 0, 0);
+                    xrs[ps] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_r, tokc * 4, 0, 0));
+                } else {
+                    xq[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo1, 0, 0));
+                    xq[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo1 + 16, 0, 0));
+                    xq[ps][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, vo2, 0, 0));
+                }
                 dq[ps][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo1, 0, 0));
                 dq[ps][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo1 + 16, 0, 0));
                 dq[ps][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_d, vo2, 0, 0));
@@ -181,7 +199,7 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
                 float v[12], d1[12], dn[12];
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    v[i] = valid ? xq[ps][i >> 2][i & 3] : 0.f;
+                    if constexpr (!XNB) v[i] = valid ? xq[ps][i >> 2][i & 3] : 0.f;
                     d1[i] = valid ? dq[ps][i >> 2][i & 3] : 0.f;
                     dn[i] = 0.f;
                 }
@@ -204,26 +222,49 @@ __global__ __launch_bounds__(512, 2) void block_bwd_ln1mlp_kernel(LnMlpArgs a) {
 #pragma unroll
                     for (int i = 0; i < 12; ++i) dn[i] = 0.f;
                 }
-                float s = 0.f;
+                float rstd;
+                if constexpr (XNB) {
+                    // xhat from the forward's own LN1 row: (row - beta) / gamma = row * ig - beta * ig; the row's rstd from its statistics
+                    // buffer.  (The table index is opaque per pass: left visible, the 24 table values are hoisted out of the walk and spilled.)
+                    int pq = p;
+                    asm volatile("" : "+v"(pq));
 #pragma unroll
-                for (int i = 0; i < 12; ++i) s += v[i];
-                const float mean = oct_sum5(s) * (1.f / 96.f);
-                float vs = 0.f;
+                    for (int q = 0; q < 3; ++q) {
+                        const int f0 = q < 2 ? 8 * pq + 4 * q : 64 + 4 * pq;
+                        const f32x4 i4 = *reinterpret_cast<const f32x4*>(&sm.ig1[f0]), b4 = *reinterpret_cast<const f32x4*>(&sm.bet1[f0]);
+                        const unsigned u0 = q < 2 ? xna[ps][2 * q] : xnb[ps][0], u1 = q < 2 ? xna[ps][2 * q + 1] : xnb[ps][1];
+                        // (rows past the end hold row 0's finite values: their dn and rstd are zero, nothing of them is used)
+                        v[4 * q] = fmaf(__uint_as_float(u0 << 16), i4[0], -b4[0]);
+                        v[4 * q + 1] = fmaf(__uint_as_float(u0 & 0xffff0000u), i4[1], -b4[1]);
+                        v[4 * q + 2] = fmaf(__uint_as_float(u1 << 16), i4[2], -b4[2]);
+                        v[4 * q + 3] = fmaf(__uint_as_float(u1 & 0xffff0000u), i4[3], -b4[3]);
+                    }
+                    rstd = xrs[ps];
+                } else {
+                    float s = 0.f;
 #pragma unroll
-                for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
-                const float rstd = rsqrtf(oct_sum5(vs) * (1.f / 96.f) + 1e-5f);
+                    for (int i = 0; i < 12; ++i) s += v[i];
+                    const float mean = oct_sum5(s) * (1.f / 96.f);
+                    float vs = 0.f;
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { const float d = v[i] - mean; vs += d * d; }
+                    rstd = rsqrtf(oct_sum5(vs) * (1.f / 96.f) + 1e-5f);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) v[i] = (v[i] - mean) * rstd;
+                }
                 float g1 = 0.f, g2 = 0.f;
                 float gam[12];
                 {
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(&sm.gam1[8 * p]), gb = *reinterpret_cast<const f32x4*>(&sm.gam1[8 * p + 4]),
-                                gc = *reinterpret_cast<const f32x4*>(&sm.gam1[64 + 4 * p]);
+                    int pg = p;
+                    if (XNB) asm volatile("" : "+v"(pg));
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(&sm.gam1[8 * pg]), gb = *reinterpret_cast<const f32x4*>(&sm.gam1[8 * pg + 4]),
+                                gc = *reinterpret_cast<const f32x4*>(&sm.gam1[64 + 4 * pg]);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { gam[e] = ga[e]; gam[4 + e] = gb[e]; gam[8 + e] = gc[e]; }
                 }
 #pragma unroll
                 for (int i = 0; i < 12; ++i) {
-                    const float xh = (v[i] - mean) * rstd;
-                    v[i] = xh;
+                    const float xh = v[i];
                     dg[i] += dn[i] * xh;
                     db[i] += dn[i];
                     dn[i] *= gam[i];
@@ -560,21 +601,28 @@ int launch_block_bwd_ln1mlp(const LnMlpArgs& a, int grid, hipStream_t st) {
     const size_t smem = sizeof(LmSmem);
     const int ntiles = (int)((a.ntok + 63) / 64);
     if (grid < 1 || a.nparts < 1 || a.nparts > 4 || (long)a.nparts * a.ntok * 192 >= 0x7ffffff0L || a.ntok * 384 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;
+    const bool xnb = a.xn != nullptr;   // MSST_LN1_FROM_XN: instantiated for bf16 x1 rows only (both are the role-split forward's products)
+    if (xnb && (!a.rstd || !a.ln1_b || !a.x1_bf16)) return MSST_ERR_UNSUPPORTED;
     if (grid > ntiles) grid = ntiles;
+#ifdef MSST_B5_ONLY_BENCH   // (kernel-study compile: the bench shape's instances only, tools/kres.py)
+#define MSST_B5_FOR_ALL(X) X(4, true)
+#else
 #define MSST_B5_FOR_ALL(X) X(1, false) X(1, true) X(2, false) X(2, true) X(3, false) X(3, true) X(4, false) X(4, true)
+#endif
     if (!attr_set) {
-#define MSST_B5_ATTR1(np, dr, q, xb) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, q, xb>), \
+#define MSST_B5_ATTR1(np, dr, q, xb, xn) { hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&block_bwd_ln1mlp_kernel<np, dr, q, xb, xn>), \
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); if (e != hipSuccess) return (int)e; }
-#define MSST_B5_ATTR(np, dr) MSST_B5_ATTR1(np, dr, false, false) MSST_B5_ATTR1(np, dr, true, false) MSST_B5_ATTR1(np, dr, false, true) MSST_B5_ATTR1(np, dr, true, true)
+#define MSST_B5_ATTR(np, dr) MSST_B5_ATTR1(np, dr, false, false, false) MSST_B5_ATTR1(np, dr, true, false, false) MSST_B5_ATTR1(np, dr, false, true, false) \
+                             MSST_B5_ATTR1(np, dr, true, true, false) MSST_B5_ATTR1(np, dr, false, true, true) MSST_B5_ATTR1(np, dr, true, true, true)
         MSST_B5_FOR_ALL(MSST_B5_ATTR)
         attr_set = true;
     }
     ProfScope ps(K_BWD_LN1MLP, st);
     const bool dr = a.drop_i.thr != 0 || a.drop_p.thr != 0;
-#define MSST_B5_LAUNCH1(np, drv, q, xb) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, q, xb>), dim3(grid), dim3(512), smem, st, a)
-#define MSST_B5_LAUNCH(np, drv) if (a.nparts == np && dr == drv) { \
-        if (a.queue) { if (a.x1_bf16) MSST_B5_LAUNCH1(np, drv, true, true); else MSST_B5_LAUNCH1(np, drv, true, false); } \
-        else { if (a.x1_bf16) MSST_B5_LAUNCH1(np, drv, false, true); else MSST_B5_LAUNCH1(np, drv, false, false); } }
+#define MSST_B5_LAUNCH1(np, drv, q, xb, xn) hipLaunchKernelGGL((block_bwd_ln1mlp_kernel<np, drv, q, xb, xn>), dim3(grid), dim3(512), smem, st, a)
+#define MSST_B5_LAUNCH2(np, drv, q) { if (xnb) MSST_B5_LAUNCH1(np, drv, q, true, true); else if (a.x1_bf16) MSST_B5_LAUNCH1(np, drv, q, true, false); \
+                                      else MSST_B5_LAUNCH1(np, drv, q, false, false); }
+#define MSST_B5_LAUNCH(np, drv) if (a.nparts == np && dr == drv) { if (a.queue) MSST_B5_LAUNCH2(np, drv, true) else MSST_B5_LAUNCH2(np, drv, false) }
     MSST_B5_FOR_ALL(MSST_B5_LAUNCH)
     return (int)hipGetLastError();
 }

@@ -621,6 +621,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
         const long tok = tok_of(k, lr);
         const float* lnp = lnp_at(k);
         elem* const xn_out = step_blk(k).xn_out;
+        // statistics buffer of the step's block: [tiles][H][64] lse | [tokens] rstd of this LN1 (MSST_SAVED_RSTD: the fused row-local
+        // backward rebuilds xhat from the bf16 rows below and this value instead of re-reading x)
+        float* stats;
+        if constexpr (STACK) stats = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[blk_at(k)][BT_X + 4]));
+        else stats = a.lse_out;
         float v[24];
 #pragma unroll
         for (int i = 0; i < 6; ++i) { v[4*i] = xv[i][0]; v[4*i+1] = xv[i][1]; v[4*i+2] = xv[i][2]; v[4*i+3] = xv[i][3]; }
@@ -636,6 +641,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
         for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
         const float rstd = rsqrtf(quad_sum(vs) * (1.f / 96.f) + 1e-5f);
+        if (stats && tok >= 0 && part == 0) stats[(long)a.ntiles * H * 64 + tok] = rstd;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int f0 = 16 * i + 4 * part;

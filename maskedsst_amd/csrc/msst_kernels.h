@@ -137,6 +137,9 @@ struct Ln1BwdArgs {
 struct LnMlpArgs {
     BlockWeights w;          // block i - 1 (MLP half: w1, w1T, w2T, ln2_g, ln2_b, b1)
     const float* ln1_g;      // block i
+    const float* ln1_b;      // block i (xn path only)
+    const void* xn;          // optional: [tokens][96] bf16 LN1 rows of block i as its forward used them, with
+    const float* rstd;       //           [tokens] rstd of that LN1: xhat = (xn - ln1_b) / ln1_g replaces the read + renormalisation of x
     const float* x;          // [tokens][96] input of block i (= output of block i - 1)
     float* dx1;              // in: dx1 of block i (gradient at its mid residual); out: dx1 of block i - 1 (same rows, in place)
     const void* dxn_part;    // [nparts][tokens][96] bf16 partial d(LN1 out) of block i

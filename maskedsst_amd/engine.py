@@ -216,6 +216,47 @@ class Engine:
             if bad:
                 raise _lib.MsstError(f"msst_prep_weights skipped malformed jobs (flags {bad}): operand copies are incomplete")
             self._prep_checked = self._jobs
+        if self.prec == PREC_BF16:
+            self._ln1_guard_launch()
+
+    # ------------------------------------------------------------------ guard of MSST_LN1_FROM_XN
+    LN1_XN_MAX_RATIO = 12.0   # max |ln1_b / ln1_g|: xhat = (row - b) / g amplifies the bf16 rounding of the saved rows by 1 + |b / g| / |xhat|
+
+    def _ln1_guard_launch(self):
+        """max |ln1_b / ln1_g| over every block (inf when a gamma is 0), computed on the device from the flat parameter buffer and
+        copied to pinned host memory WITHOUT a synchronisation: read a step later (LN parameters move by <= lr per step)."""
+        if getattr(self, "_ln1_idx", None) is None or self._ln1_idx_key is not self._jobs:
+            names = [f"{s}.{l}.ln1_{k}" for k in ("g", "b") for s, l in self._layers()]
+            offs = np.array([self.fp.segments[n][0] for n in names], dtype=np.int64)
+            idx = (offs[:, None] + np.arange(96)[None, :]).reshape(2, -1)
+            self._ln1_idx = torch.from_numpy(idx).to(self.fp.flat.device)
+            self._ln1_idx_key = self._jobs
+            self._ln1_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            self._ln1_ev = None
+            self._ln1_ratio = None
+            self._ln1_calls = 0
+        self._ln1_calls += 1
+        if self._ln1_ev is not None and self._ln1_ev.query():      # the copy launched some parameter updates ago has landed: adopt its value
+            self._ln1_ratio = float(self._ln1_host[0])
+            self._ln1_ev = None
+        # a fresh value every 8th parameter update is enough (the threshold is an order of magnitude, not a margin; LN parameters
+        # move by <= lr per step); the very first call synchronises once
+        if self._ln1_ratio is not None and (self._ln1_ev is not None or self._ln1_calls % 8 != 1):
+            return
+        g = self.fp.flat[self._ln1_idx[0]]
+        b = self.fp.flat[self._ln1_idx[1]]
+        ratio = (b.abs() / g.abs()).nan_to_num(nan=float("inf")).max().reshape(1)
+        self._ln1_host.copy_(ratio, non_blocking=True)
+        self._ln1_ev = torch.cuda.Event()
+        self._ln1_ev.record()
+        if self._ln1_ratio is None:
+            self._ln1_ev.synchronize()
+            self._ln1_ratio = float(self._ln1_host[0])
+            self._ln1_ev = None
+
+    def ln1_xn_ok(self):
+        r = getattr(self, "_ln1_ratio", None)
+        return r is not None and r <= self.LN1_XN_MAX_RATIO
 
     # ------------------------------------------------------------------ forward pieces
     def tokenize(self, img, mask_u8=None, with_pos=True, emb_drop=(0.0, 0)):
@@ -289,7 +330,7 @@ class Engine:
         key = (mode, B)
         hit = self._tpw.get(key)
         if hit is None:
-            tiles = int(self.lib.msst_block_lse_floats(mode, B, self.S, self.N, 1)) // 64
+            tiles = int(self.lib.msst_block_tiles(mode, B, self.S, self.N))
             grid = max(1, min(tiles, self._cu_count(), self.max_grid if self.max_grid > 0 else tiles))
             hit = self._tpw[key] = -(-tiles // grid)
         return hit
@@ -318,6 +359,7 @@ class Engine:
         if x1 is not None:
             x1._msst_xn = xn if (wrote.value & _lib.SAVED_XN) else None
             x1._msst_lse = lse if (wrote.value & _lib.SAVED_LSE) else None
+            x1._msst_rstd = bool(wrote.value & _lib.SAVED_RSTD) and x1._msst_lse is not None   # rstd of LN1 rides in the tail of the statistics buffer
         acts.append(y)
         x1s.append(x1)
 
@@ -357,6 +399,7 @@ class Engine:
             if save:
                 x1[j]._msst_xn = xn[j] if (wrote.value & _lib.SAVED_XN) else None
                 x1[j]._msst_lse = lse[j] if (lse is not None and (wrote.value & _lib.SAVED_LSE)) else None
+                x1[j]._msst_rstd = bool(wrote.value & _lib.SAVED_RSTD) and x1[j]._msst_lse is not None
                 x1s.append(x1[j])
             else:
                 x1s.append(None)
@@ -455,6 +498,14 @@ class Engine:
         chain = (self.prec == PREC_BF16 and flags == 0 and dab is not None and all(t is not None for t in xns)
                  and nparts <= 4 and os.environ.get("MSST_BWD_CHAIN", "1") != "0" and len(layers) > 0
                  and ntok * 384 < 2 ** 31 - 16 and nparts * ntok * 192 < 2 ** 31 - 16)   # 32-bit buffer offsets in the fused launch
+        # MSST_LN1_FROM_XN (round 6): the fused LN1 + MLP launch rebuilds xhat of LN1 from the saved bf16 LN1 rows and the saved rstd
+        # instead of re-reading the fp32 block input (192 of 2304 bytes per token less) -- when the forward saved both for every block,
+        # and the LN1 parameters allow the division by gamma (ln1_xn_ok: max |beta / gamma| <= 12, checked on the device a step behind)
+        xnflag = 0
+        if (chain and x1_bf16 and os.environ.get("MSST_LN1_XN", "1") != "0" and all(getattr(t, "_msst_rstd", False) for t in x1s)
+                and self.ln1_xn_ok()):
+            xnflag = _lib.LN1_FROM_XN
+        self.last_bwd_ln1_from_xn = bool(xnflag)
         if chain:
             # dynamic tile queues (attach_data_parallel sets self.tile_queue; MSST_TILE_QUEUE=1 forces them): see include/msst.h
             queue = None
@@ -488,7 +539,7 @@ class Engine:
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
                     _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab_i), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec | x1flag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab),
+                    B, S, N, H, self.prec | x1flag | xnflag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab),
                     1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
                 if not defer:
@@ -506,17 +557,41 @@ class Engine:
             return dx0
         g = dy
         other = torch.empty_like(dy)
+        ws = (dx1, part, slab, dab)
         for i in reversed(range(len(layers))):
-            sname, l = layers[i]
-            mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
-            _lib.check(self.lib.msst_block_bwd(
-                ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(acts[i]), _p(x1s[i]), _p(g), _p(other),
-                _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
-                self.prec | flags | x1flag,
-                drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab), _stream()), "msst_block_bwd")
+            self.block_bwd_single(i, acts[i], x1s[i], g, other, drop=drop, ws=ws)
             g, other = other, g
-            self._fire(f"{sname}.{l}")
+            self._fire(f"{layers[i][0]}.{layers[i][1]}")
         return g
+
+    def block_bwd_single(self, i, x, x1, dy, dx=None, drop=(0.0, 0), ws=None):
+        """Backward of block i alone (msst_block_bwd: MLP half, attention half, LN1 backward, slab reduction): x = the block's input,
+        x1 = its saved mid residual (with the LN1 rows / statistics its forward attached), dy = the gradient at its output -> dx;
+        the block's parameter gradients land in the flat gradient buffer.  The unchained loop of blocks_bwd runs on it; the parity tests
+        call it block by block with the ORACLE's activations and gradients (no error carried from block to block)."""
+        B = dy.shape[0]
+        S, N, H = self.S, self.N, self.enc.heads
+        dev = dy.device
+        ntok = B * S * N
+        if ws is None:
+            esz = 4 if self.prec == PREC_F32 else 2
+            ws = (torch.empty(ntok * 96, dtype=torch.float32, device=dev), torch.empty(H * ntok * 96 * esz, dtype=torch.uint8, device=dev),
+                  torch.empty(self.grid_rows * (3 * MLP_SLAB + LN1_SLAB) + self.attn_chunks * H * ATTN_SLAB, dtype=torch.float32, device=dev),
+                  torch.empty(ntok * 96, dtype=torch.bfloat16, device=dev) if self.prec != PREC_F32 else None)
+        dx1, part, slab, dab = ws
+        if dx is None:
+            dx = torch.empty_like(dy)
+        sname, l = self._layers()[i]
+        mode = MODE_SPATIAL if sname == "spatial" else MODE_SPECTRAL
+        if x1.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("saved x1 rows must be fp32 or bf16")
+        x1flag = _lib.X1_BF16 if x1.dtype == torch.bfloat16 else 0
+        _lib.check(self.lib.msst_block_bwd(
+            ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(x), _p(x1), _p(dy), _p(dx),
+            _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
+            self.prec | _kernel_flags() | x1flag,
+            drop[0], drop[1], i, _p(getattr(x1, "_msst_xn", None)), _p(getattr(x1, "_msst_lse", None)), _p(dab), _stream()), "msst_block_bwd")
+        return dx
 
     def tokenize_bwd(self, img, mask_u8, dx0, emb_drop=(0.0, 0), with_pos=True):
         """with_pos=False: gradients of the embedding / its two LayerNorms only (the position table and the mask

@@ -442,7 +442,12 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     TS = 64 // N
     nseq = B * S
     ntiles = (nseq + TS - 1) // TS
-    got = lse.reshape(ntiles, H, 64)[:, :, :TS * N].reshape(ntiles, H, TS, N).permute(0, 2, 1, 3).reshape(ntiles * TS, H, N)[:nseq]
+    assert lse.numel() == ntiles * H * 64 + B * S * N          # [tiles][heads][64] lse | [tokens] rstd of LN1 (MSST_VERSION 104)
+    rstd_got = lse[ntiles * H * 64:]
+    x_in = o1["tok_masked"].float().reshape(B * S * N, 96)
+    rstd_ref = torch.rsqrt(x_in.var(dim=-1, unbiased=False) + 1e-5)
+    assert float(((rstd_got - rstd_ref).abs() / rstd_ref).max()) < 1e-5
+    got = lse[:ntiles * H * 64].reshape(ntiles, H, 64)[:, :, :TS * N].reshape(ntiles, H, TS, N).permute(0, 2, 1, 3).reshape(ntiles * TS, H, N)[:nseq]
     err = float((got - ref).abs().max())
     # bf16 q / k (three significant digits) in scores of magnitude ~1: measured ~4e-3; the scores of the peaky cases are 16x larger
     assert err < 2e-2 * float(cfg.get("qkv_scale", 1)) ** 2, err
@@ -461,7 +466,7 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     from oracle import transformer_forward
     from dropout import make_drop_fn
     ocfg = oracle_cfg_from(cfg)
-    blk = {k: v.clone().requires_grad_(True) for k, v in params.items() if ".layers." in k}
+    blk = {k: v.clone().requires_grad_(True) for k, v in params.items() if "spatial_spectral_transformer" in k}
     tok = o1["tok_masked"].detach().float().cpu().requires_grad_(True)
     y = transformer_forward(blk, tok, ocfg, drop_fn=make_drop_fn(drop[0], drop[1], ocfg.S, ocfg.N, ocfg.heads) if drop[0] else None)
     y.backward(run.dy.cpu())
@@ -483,6 +488,96 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     else:                       # PLACEHOLDER bars until measured on the device
         assert e_dx < 0.2, e_dx
         assert worst < 0.2, (worst, bad[:3])
+
+
+XN_CASES = [dict(bands=200, depth=2, B=5), dict(bands=50, depth=3, B=4), dict(bands=30, depth=2, B=3, image_size=6, mask_patch_size=2),
+            dict(bands=200, depth=2, B=256), dict(bands=20, depth=2, B=3, heads=4), dict(bands=50, depth=12, B=8, qkv_scale=4)]
+
+
+@pytest.mark.parametrize("drop", [(0.0, 0), (0.1, 4242)], ids=["nodrop", "drop0.1"])
+@pytest.mark.parametrize("cfg", XN_CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+def test_ln1_backward_from_saved_rows(cfg, drop, monkeypatch):
+    """Round 6 (MSST_LN1_FROM_XN): the fused LN1 + MLP launch of the chained backward takes xhat of LN1 (reference
+    vit_spatial_spectral.py:22-29) from the forward's saved bf16 LN1 rows -- xhat = (row - beta) / gamma -- and rstd from the tail of
+    the statistics buffer, instead of re-reading and re-normalising the fp32 block input.  Against the same backward on the fp32 rows
+    (MSST_LN1_XN=0), same operands and masks: dx0 and every gradient tensor at the bf16 level; and against the oracle's autograd
+    through the same blocks it may not sit further away than the fp32-row form (10 % slack).  LN1 parameters off their initial
+    values (gamma 0.5 .. 1.5, beta +-0.3), as after training."""
+    from oracle import transformer_forward
+    from dropout import make_drop_fn
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    torch.manual_seed(3)
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if n.endswith(".0.norm.weight"):
+                q.copy_(0.5 + torch.rand(96)); params[n].copy_(q.cpu())
+            if n.endswith(".0.norm.bias"):
+                q.copy_(0.6 * torch.rand(96) - 0.3); params[n].copy_(q.cpu())
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1], drop=drop)
+    torch.manual_seed(11)
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+
+    def run(flag):
+        monkeypatch.setenv("MSST_LN1_XN", flag)
+        eng.fp.grad.zero_()
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone(), drop=drop)
+        torch.cuda.synchronize()
+        return dx0.clone(), eng.fp.grad.clone(), eng.last_bwd_ln1_from_xn
+
+    dx_n, g_n, used_n = run("1")
+    dx_x, g_x, used_x = run("0")
+    monkeypatch.delenv("MSST_LN1_XN")
+    H = cfg.get("heads", 8)
+    assert used_n == (H == 8) and not used_x     # the role-split forward (8 heads) saves rstd; other head counts keep the fp32 rows
+    e_dx = rel_l2(dx_n, dx_x)
+    worst = 0.0
+    for name, q in eng.trainable():
+        b = eng.fp.view(name, g_x)
+        if float(b.abs().max()) > 0.0:
+            worst = max(worst, rel_l2(eng.fp.view(name, g_n), b))
+    ocfg = oracle_cfg_from(cfg)
+    blk = {k: v.clone().requires_grad_(True) for k, v in params.items() if "spatial_spectral_transformer" in k}
+    tok = out["tok_masked"].detach().float().cpu().requires_grad_(True)
+    y = transformer_forward(blk, tok, ocfg, drop_fn=make_drop_fn(drop[0], drop[1], ocfg.S, ocfg.N, ocfg.heads) if drop[0] else None)
+    y.backward(dy.cpu())
+    flat = {id(q): n for n, q in eng.trainable()}
+    vs = {}
+    for tag, dxk, gk in (("xn", dx_n, g_n), ("x", dx_x, g_x)):
+        ge = {pn: rel_l2(eng.fp.view(flat[id(q)], gk), blk[pn].grad) for pn, q in model.named_parameters() if pn in blk}
+        vs[tag] = dict(dx=rel_l2(dxk, tok.grad), worst_grad=max(ge.values()), ln1=max(v for k, v in ge.items() if ".0.norm." in k))
+    record("ln1_backward_from_saved_rows", cfg=cfg, drop=list(drop), dx=e_dx, worst_grad=worst,
+           oracle_xn_dx=vs["xn"]["dx"], oracle_x_dx=vs["x"]["dx"], oracle_xn_worst_grad=vs["xn"]["worst_grad"],
+           oracle_x_worst_grad=vs["x"]["worst_grad"], oracle_xn_ln1_grad=vs["xn"]["ln1"], oracle_x_ln1_grad=vs["x"]["ln1"])
+    if H == 8:
+        assert e_dx < 2e-3 and worst < 8e-3, (e_dx, worst)          # PLACEHOLDER bars until measured on the device
+        assert vs["xn"]["dx"] < 1.1 * vs["x"]["dx"] + 1e-4 and vs["xn"]["worst_grad"] < 1.1 * vs["x"]["worst_grad"] + 1e-4, vs
+
+
+def test_ln1_from_saved_rows_guard(monkeypatch):
+    """The division by gamma is refused when it would amplify the rows' bf16 rounding (max |beta / gamma| > 12, or a gamma of 0): the
+    engine then keeps the fp32 block input for LN1's backward -- no flag, same results as MSST_LN1_XN=0 bit for bit."""
+    cfg = dict(bands=50, depth=2, B=4)
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    with torch.no_grad():
+        for n, q in model.named_parameters():
+            if n.endswith("layers.1.0.norm.weight"):
+                q[5] = 0.0
+    eng = model.engine()
+    masks = model.draw_masks(cfg["B"])
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    dy = torch.randn_like(out["enc_out"]) * 1e-3
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MSST_LN1_XN", flag)
+        eng.fp.grad.zero_()
+        dx0 = eng.blocks_bwd(out["acts"], out["x1s"], dy.clone())
+        torch.cuda.synchronize()
+        assert not eng.last_bwd_ln1_from_xn
+        res[flag] = (dx0.clone(), eng.fp.grad.clone())
+    assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+    assert torch.isfinite(res["1"][1]).all()
 
 
 def test_bf16_x1_rows_with_a_large_row_offset(monkeypatch):
