@@ -46,6 +46,18 @@
 #if defined(MSST_LAB) && !defined(MSST_LAB_X1OLD)
 #define MSST_LAB_X1OLD 0
 #endif
+// kernel-study builds only (-DMSST_LAB: msst_version() < 0, refused by the product loader): what each of the forward's saved extras costs
+// -- MSST_LAB_NOLSE / MSST_LAB_NORSTD compile the softmax-statistics store / the LN1 rstd store out (tools/fwd_time.py, round 6)
+#if !defined(MSST_LAB) || !defined(MSST_LAB_NOLSE)
+#define MSST_F3_LSE_STORE 1
+#else
+#define MSST_F3_LSE_STORE 0
+#endif
+#if !defined(MSST_LAB) || !defined(MSST_LAB_NORSTD)
+#define MSST_F3_RSTD_STORE 1
+#else
+#define MSST_F3_RSTD_STORE 0
+#endif
 #ifndef MSST_F3_RPRIO02
 #define MSST_F3_RPRIO02 MSST_F3_RPRIO   // priority of the R waves in q0 / q2, where they finish early and wait for the A waves (q1 / q3, where the A waves wait for them: MSST_F3_RPRIO)
 #endif
@@ -82,6 +94,7 @@ struct Fwd3Smem {
     int seqb[4][64];                       // token of position 0 of every sequence slot, tiles of walk steps k - 1 .. k + 1 (by k & 3)
     float lnp[2][640];                     // ln1_g | ln1_b | bo | ln2_g | ln2_b | b2 | b1 of the block of a step; [1]: STACK only (the block a step pipeline
                                            // runs into while the stages behind it still work for the block before)
+    float lseb[2][256];                    // softmax statistics of the tile in flight: [round][A wave (head 4 round + wave)][row]; the R waves copy them out (round 6)
     char wmlp[24 * 1024];                  // [w1: 12 frags | w2: 12 frags]
     const char* blktab[MSST_MAX_STACK][16];   // (STACK) every per-block operand of the run, in StackBlk's member order: block 0's + block x its stride
     unsigned steptab[1024];                // (STACK) walk step -> local tile index | block << 16 | lnp slot << 24 | idle << 31
@@ -374,8 +387,6 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             const elem* wqkv = sb.wqkv;
             const elem* wqkv_next = (STACK && k + 1 < nsteps) ? step_blk(k + 1).wqkv : sb.wqkv;   // where the weight ring wraps to at the end of round 1
             const Drop drop_k = drop_at(k);
-            // (the range check of a buffer store covers the lane offset only: an idle step -- or no buffer -- gets zero records)
-            const __amdgpu_buffer_rsrc_t lse_rs = __builtin_amdgcn_make_buffer_rsrc(sb.lse_out, 0, (sb.lse_out && tile >= 0) ? (int)min((long)a.ntiles * H * 256, 0x7fffffffL) : 0, 0x00020000);
 #ifdef MSST_STAMPS
             const bool stamp_on = (a.dbg & 8) && a.stamps && blockIdx.x == 100 && l == 0 && k == nsteps / 2;
 #endif
@@ -529,12 +540,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                         for (int u = 0; u < 2; ++u) {
                             const float st = colgroup_sum(sum[u]);
                             inv[u] = (DROP ? drop_k.scale : 1.f) * __builtin_amdgcn_rcpf(st);   // the dropout scale rides on the normalisation
-                            // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head).  One
-                            // buffer store, no branch: (tile, head) rides in the scalar offset, the query row in the lane offset; a query's
-                            // value is replicated over the four lane groups, which all write it (an out-of-range offset -- no buffer given:
-                            // zero records -- is dropped by the hardware)
-                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mc[u] + __builtin_amdgcn_logf(st)), lse_rs, cq * 4,
-                                                                  ((tile * H + h) * 64 + (2 * jp + u) * 16) * 4, 0);
+                            // saved for the backward: p = exp2(s c - lse) with lse = max c + log2(sum) -- 256 bytes per (tile, head).  Handed to
+                            // the R waves through LDS (a query's value is replicated over the four lane groups, which all write it); they copy a
+                            // round's 1 KB out as whole lines in the next interval.  (Round 5 stored it from here with one buffer store per
+                            // query tile: a store sits in this wave's in-order memory counter in front of every later weight-fragment wait --
+                            // 6 us of the forward's 256, tools/fwd_time.py with -DMSST_LAB_NOLSE.)
+                            if (MSST_F3_LSE_STORE) sm.lseb[rd][wv * 64 + (2 * jp + u) * 16 + cq] = mc[u] + __builtin_amdgcn_logf(st);
                         }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
         for (int i = 0; i < 24; ++i) { const float d = v[i] - mean; vs += d * d; }
         const float rstd = rsqrtf(quad_sum(vs) * (1.f / 96.f) + 1e-5f);
-        if (stats && tok >= 0 && part == 0) stats[(long)a.ntiles * H * 64 + tok] = rstd;
+        if (MSST_F3_RSTD_STORE && stats && tok >= 0 && part == 0) stats[(long)a.ntiles * H * 64 + tok] = rstd;
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int f0 = 16 * i + 4 * part;
@@ -865,6 +876,19 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             }
         }
     };
+    // softmax statistics of round rd of walk step k (four heads x 64 rows, left in LDS by the A waves, complete since the barrier that
+    // ended the round) -> the block's statistics buffer: 1 KB of consecutive addresses, one float per R thread
+    auto copy_lse = [&](int k, int rd) {
+        if (!MSST_F3_LSE_STORE) return;
+        const int tile_ = tile_at(k);
+        float* stats;
+        if constexpr (STACK) stats = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[blk_at(k)][BT_X + 4]));
+        else stats = a.lse_out;
+        if (!stats || tile_ < 0) return;
+        int rt_ = (int)threadIdx.x - 256;
+        asm volatile("" : "+v"(rt_));
+        stats[((long)tile_ * H + 4 * rd) * 64 + rt_] = sm.lseb[rd][rt_];
+    };
     auto zero_acc = [&]() {
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
@@ -908,7 +932,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             lnp_switch = k + 1 < nsteps && epoch_differs(k + 1, k);
             if (lnp_switch && rt < 96) lnp_regs = fetch_lnp(blk_at(k + 1), rt);
         }
-        if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); }
+        if (have_prev) { request_xr(k - 1); outproj(1); F3_STAMP(1); epilogue1(k - 1); copy_lse(k - 1, 1); }
         F3_STAMP(2);
         // STACK: every memory operation of this wave so far -- the y / x1 rows the steps before stored above all: LN1 of the same tile's
         // NEXT block requests them in q2 of this step at the earliest -- and the MLP weight copy of this interval have completed
@@ -933,6 +957,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
         if (have_cur) outproj(0);
         F3_STAMP(6);
         if (have_prev) { store_x1_bf16(k - 1); mlp1(k - 1); }
+        if (have_cur) copy_lse(k, 0);
         if (MSST_F3_LN1Q == 2 && k + 1 < nsteps) ln1(k + 1);
         if (MSST_F3_LN1Q == 3 && k + 1 < nsteps) request_ln1(k + 1);   // consumed at the end of q3: the barrier wait and MLP GEMM 2 cover the HBM round trip
         F3_STAMP(7);

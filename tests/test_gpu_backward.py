@@ -479,15 +479,18 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     record("saved_softmax_statistics", cfg=cfg, drop=list(drop), lse_abs_err=err, dx=e_dx, worst_grad=worst,
            oracle_lse_dx=vs_oracle["lse"]["dx"], oracle_own_dx=vs_oracle["own"]["dx"],
            oracle_lse_worst_grad=vs_oracle["lse"]["worst_grad"], oracle_own_worst_grad=vs_oracle["own"]["worst_grad"])
-    # the lse path may not sit further from the exact gradient than the self-normalising one (10 % slack for rounding luck)
+    # the lse path may not sit further from the exact gradient than the self-normalising one (measured: equal to three digits in
+    # every case, peaky ones included -- dx 5.78e-2 vs 5.77e-2 at depth 2 x4; 10 % / 20 % slack for rounding luck)
     assert vs_oracle["lse"]["dx"] < 1.1 * vs_oracle["own"]["dx"] + 1e-4, vs_oracle
-    assert vs_oracle["lse"]["worst_grad"] < 1.1 * vs_oracle["own"]["worst_grad"] + 1e-4, vs_oracle
+    assert vs_oracle["lse"]["worst_grad"] < 1.2 * vs_oracle["own"]["worst_grad"] + 1e-4, vs_oracle
     if not peaky:
         assert e_dx < 1.5e-3, e_dx
         assert not bad, bad
-    else:                       # PLACEHOLDER bars until measured on the device
-        assert e_dx < 0.2, e_dx
-        assert worst < 0.2, (worst, bad[:3])
+    else:
+        # peaky rows: the two backwards differ by the fp32 summation order of their scores, amplified by the model (measured: dx
+        # 7.3e-3, worst gradient 9.4e-3 at depth 2; 1.6e-2 / 2.1e-2 through the 24 blocks of the depth-12 fixture shape)
+        assert e_dx < 6e-2, e_dx
+        assert worst < 8e-2, (worst, bad[:3])
 
 
 XN_CASES = [dict(bands=200, depth=2, B=5), dict(bands=50, depth=3, B=4), dict(bands=30, depth=2, B=3, image_size=6, mask_patch_size=2),
@@ -551,8 +554,11 @@ def test_ln1_backward_from_saved_rows(cfg, drop, monkeypatch):
            oracle_xn_dx=vs["xn"]["dx"], oracle_x_dx=vs["x"]["dx"], oracle_xn_worst_grad=vs["xn"]["worst_grad"],
            oracle_x_worst_grad=vs["x"]["worst_grad"], oracle_xn_ln1_grad=vs["xn"]["ln1"], oracle_x_ln1_grad=vs["x"]["ln1"])
     if H == 8:
-        assert e_dx < 2e-3 and worst < 8e-3, (e_dx, worst)          # PLACEHOLDER bars until measured on the device
-        assert vs["xn"]["dx"] < 1.1 * vs["x"]["dx"] + 1e-4 and vs["xn"]["worst_grad"] < 1.1 * vs["x"]["worst_grad"] + 1e-4, vs
+        # measured on MI355X: dx <= 9.4e-4, worst gradient tensor <= 4.0e-3 (the x4 depth-12 shape, which amplifies: 1.6e-2 / 2.0e-2);
+        # against the oracle the two forms are equal to three digits in dx (1.10e-3 both) and within +-15 % on their worst tensor
+        bar_dx, bar_g = (6e-2, 8e-2) if "qkv_scale" in cfg else (3e-3, 1.2e-2)
+        assert e_dx < bar_dx and worst < bar_g, (e_dx, worst)
+        assert vs["xn"]["dx"] < 1.1 * vs["x"]["dx"] + 1e-4 and vs["xn"]["worst_grad"] < 1.3 * vs["x"]["worst_grad"] + 1e-4, vs
 
 
 def test_ln1_from_saved_rows_guard(monkeypatch):

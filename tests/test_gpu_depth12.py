@@ -122,10 +122,14 @@ BF16_BARS = {
     "simmim_200b_L12_B4.npz": dict(loss=2.8e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
     "simmim_50b_L12_B8.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
     "simmim_50b_L12_B8_zeropad.npz": dict(loss=9e-4, stage=1.2e-2, dx0=1e-2, grad=1.9e-2, cos=0.9999),
-    # peaky rows: a bf16 q / k pair (2^-9 relative each) moves a logit of 30 by ~0.06, i.e. a probability by 6 %: the bf16 noise of
-    # these cases is an order of magnitude above the uniform-attention cases' by construction (PLACEHOLDER bars until measured)
-    "simmim_200b_L12_B4_qkv4.npz": dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5, cos=0.9),
-    "simmim_50b_L12_B8_qkv4.npz": dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5, cos=0.9),
+    # peaky rows END TO END: a bf16 q / k pair (2^-9 relative each) moves a logit of 30 by ~0.06, i.e. a probability by 6 %, and the
+    # x4 models amplify every error ~40x through their 24 blocks (fp32 kernels: 2e-5 of max at the encoder output instead of 6e-7).
+    # Measured: loss 4e-5 / 2e-3, stages 12 % / 22 % of max, dx0 0.37 / 0.58 rel-L2, worst gradient tensor 0.60 / 0.67, cosine 0.96 /
+    # 0.835 -- the conditioning of the MODEL in bf16, not a kernel error: block by block on the oracle's own activations the same
+    # kernels sit at 0.5 % (forward) / 1.3 % (backward), test_blocks_teacher_forced_on_peaky_rows.  The numbers are recorded; the bars
+    # here only catch a broken kernel (NaN, wrong masks, a wrong scale: cosine < 0.5).
+    "simmim_200b_L12_B4_qkv4.npz": dict(loss=1e-2, stage=1.0, dx0=2.0, grad=3.0, cos=0.5),
+    "simmim_50b_L12_B8_qkv4.npz": dict(loss=1e-2, stage=1.0, dx0=2.0, grad=3.0, cos=0.5),
 }
 
 
@@ -187,13 +191,15 @@ def test_depth12_bf16_vs_oracle(name):
     assert gerr[worst_name] < bars["grad"], (worst_name, gerr[worst_name])
 
 
-# teacher-forced bars (bf16, per block): PLACEHOLDER until measured on the device
-TF_BARS = dict(y=5e-2, dx=5e-2, grad=8e-2)
+# teacher-forced bars (bf16, per block; rel-L2): 3.5x the values measured on MI355X -- forward output 4.7e-3, input gradient 1.27e-2,
+# worst parameter-gradient tensor of a block 1.45e-2 (3x the randomly initialised models': peaky rows); with dropout 0.1 (the
+# kernels' masks fed to the oracle) the same within 10 %.  fp32 kernels: 8.9e-7 / 1.6e-6 / 1.9e-6 against bars of 1e-4 / 2e-4 / 2e-4.
+TF_BARS = dict(y=1.6e-2, dx=4.5e-2, grad=5e-2)
 
 
-@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+@pytest.mark.parametrize("prec,p_drop", [("bf16", 0.0), ("bf16", 0.1), ("fp32", 0.0)], ids=["bf16", "bf16-drop0.1", "fp32"])
 @pytest.mark.parametrize("name", PEAKY)
-def test_blocks_teacher_forced_on_peaky_rows(name, prec):
+def test_blocks_teacher_forced_on_peaky_rows(name, prec, p_drop):
     """Round 6: the benchmarked bf16 block kernels on PEAKY attention rows, block by block.  Through 24 blocks
     of the x4 fixtures every rounding error is amplified ~40x (fp32 kernels: 2e-5 of max at the encoder output instead of 6e-7), so
     an end-to-end bf16 comparison says little (measured: 12-22 % of max, cosine 0.84-0.96 -- test_depth12_bf16_vs_oracle records
@@ -204,6 +210,7 @@ def test_blocks_teacher_forced_on_peaky_rows(name, prec):
     attention backward that consumes them are the kernels exercised (bf16); fp32: the template kernels at 1e-4 / 2e-4."""
     import oracle.model as om
     from oracle import simmim_forward
+    from dropout import make_drop_fn
     g = load_golden(name)
     cfg = g["cfg"]
     model, params, x = build_product(cfg, precision=prec, device="cuda")
@@ -211,6 +218,7 @@ def test_blocks_teacher_forced_on_peaky_rows(name, prec):
     check_masks_against_fixture(masks, g)
     ocfg = oracle_cfg_from(cfg)
     B, S, N, T = cfg["B"], ocfg.S, ocfg.N, ocfg.T
+    drop = (p_drop, 911) if p_drop else (0.0, 0)
     for p in params.values():
         p.requires_grad_(True)
     ins = []
@@ -223,7 +231,8 @@ def test_blocks_teacher_forced_on_peaky_rows(name, prec):
 
     om.block = recording_block
     try:
-        ref = simmim_forward(params, x, ocfg, masks=masks)
+        ref = simmim_forward(params, x, ocfg, masks=masks,
+                             drop_fn=make_drop_fn(drop[0], drop[1], ocfg.S, ocfg.N, ocfg.heads) if p_drop else None)
         ref["enc_out"].retain_grad()
         ref["loss"].backward()
     finally:
@@ -247,10 +256,10 @@ def test_blocks_teacher_forced_on_peaky_rows(name, prec):
         dy_ref = to_tok(ins[i + 1].grad, i + 1) if i + 1 < 2 * L else ref["enc_out"].grad
         dx_ref = to_tok(ins[i].grad, i)
         acts, x1s = [x_i], []
-        eng._fwd_block(acts, x1s, i, True, (0.0, 0), bf, bf, 0)
+        eng._fwd_block(acts, x1s, i, True, drop, bf, bf, 0)
         e_y = rel_l2(acts[1], y_ref) if bf else relerr(acts[1], y_ref)
         eng.fp.grad.zero_()
-        dx = eng.block_bwd_single(i, x_i, x1s[0], dy_ref.cuda().contiguous())
+        dx = eng.block_bwd_single(i, x_i, x1s[0], dy_ref.cuda().contiguous(), drop=drop)
         torch.cuda.synchronize()
         e_dx = rel_l2(dx, dx_ref) if bf else relerr(dx, dx_ref)
         stack, l = ("1", i) if i < L else ("3", i - L)
@@ -263,7 +272,7 @@ def test_blocks_teacher_forced_on_peaky_rows(name, prec):
                     e_g, worst_at["grad"] = e, pname
         for k, e in (("y", e_y), ("dx", e_dx), ("grad", e_g)):
             worst[k] = max(worst[k], e)
-    record("blocks_teacher_forced_peaky", fixture=name, prec=prec, worst_y=worst["y"], worst_dx=worst["dx"], worst_grad=worst["grad"],
+    record("blocks_teacher_forced_peaky", fixture=name, prec=prec, p_drop=p_drop, worst_y=worst["y"], worst_dx=worst["dx"], worst_grad=worst["grad"],
            worst_grad_name=worst_at.get("grad", ""))
     if bf:
         assert worst["y"] < TF_BARS["y"] and worst["dx"] < TF_BARS["dx"] and worst["grad"] < TF_BARS["grad"], worst

@@ -57,8 +57,11 @@ def test_dropout_fwd_bwd_fp32_same_masks(cfg):
 # bars 3-4x measured on MI355X (profiles/r0N_parity_measured.jsonl): loss 2.0e-4, enc_out 3.1e-3 max-norm, dx0 3.0e-3 rel-L2,
 # worst parameter-gradient tensor 5.2e-3 rel-L2 (median 2.7e-3)
 BF16_DROP_BARS = dict(loss=7e-4, stage=1.1e-2, dx0=1.05e-2, grad=1.8e-2)
-# peaky attention rows (to_qkv.weight x4, tests/test_gpu_depth12.py): PLACEHOLDER bars until measured on the device
-BF16_DROP_BARS_PEAKY = dict(loss=5e-2, stage=0.5, dx0=0.5, grad=0.5)
+# peaky attention rows (to_qkv.weight x4, tests/test_gpu_depth12.py) END TO END: the x4 model amplifies every bf16 rounding ~40x through
+# its 24 blocks -- measured: loss 3.3e-4, encoder output 34 % of max, dx0 1.0 rel-L2, worst gradient tensor 1.3 -- which is the model's
+# conditioning in bf16 (the same kernels block by block on the oracle's activations, with these masks: 0.5 % / 1.3 %,
+# test_gpu_depth12.py::test_blocks_teacher_forced_on_peaky_rows[bf16-drop0.1]).  Recorded; the bars only catch NaN-class failures.
+BF16_DROP_BARS_PEAKY = dict(loss=1e-2, stage=2.0, dx0=4.0, grad=6.0)
 
 
 @pytest.mark.parametrize("qkv_scale", [None, 4], ids=["init", "peaky-x4"])
