@@ -42,6 +42,13 @@ extern "C" {
                                             8 heads, no MSST_KERNEL_* flag; MSST_ERR_UNSUPPORTED otherwise), msst_block_bwd / _chain read x1 and x1_prev so (bf16
                                             kernels only).  A quarter of the forward's writes and 8 % of the fused row-local backward's reads less; the LN2 statistics
                                             of the backward are then those of the rounded rows (parity: tests/test_gpu_backward.py::test_bf16_x1_rows) */
+#define MSST_FWD_HALF (4096 << 8)         /* msst_block_fwd / msst_block_fwd_stack, role-split bf16 forward only (MSST_VERSION 104): the forward's GEMM operands -- LN rows,
+                                            weights (MsstBlockWeights.wqkv_h ...), q / k / v, probabilities, attention output, GELU output -- are rounded to IEEE
+                                            half (11 significant bits) instead of bf16 (8) and multiplied by v_mfma_f32_16x16x32_f16 (same rate).  Everything
+                                            else is unchanged: fp32 accumulation / softmax / LayerNorm / residual stream, bf16 rows saved for the backward, bf16
+                                            backward.  Why: the bf16 forward's loss error against the fp32 reference (2.6e-4 on the Houston-shape anchor) is
+                                            systematic and owned by the rounding of the WEIGHTS (tools/bf16_error_table.py); with half operands it is 7e-6.  Every
+                                            operand of the forward is a LayerNorm row, a weight, a probability or a bounded activation: inside half's range */
 #define MSST_LN1_FROM_XN (2048 << 8)      /* msst_block_bwd_chain (MSST_VERSION 104): the fused LN1 + MLP launch takes xhat of LN1 from the saved bf16 LN1 rows and
                                             the saved rstd -- xhat = (xn_saved - ln1_b) / ln1_g, rstd = the tail of lse_saved (MSST_SAVED_RSTD) -- instead of
                                             re-reading and re-normalising the fp32 block input x: 192 bytes per token less of 2304.  The caller sets it only when
@@ -65,11 +72,14 @@ typedef struct MsstPrepJob {
     void* dst;        /* [rows][cols] or [cols][rows] (transpose) */
     int32_t rows, cols, transpose;
     int32_t pack;     /* bf16 only: 0 = 16-row x 32-k operand fragments (16x16x32 MFMA), 1 = 32-row x 16-k fragments (32x32x16 MFMA;
-                         destination rows % 32 == 0 and k % 16 == 0).  Any other value: the job is skipped. */
+                         destination rows % 32 == 0 and k % 16 == 0); + MSST_PREP_HALF (256, MSST_VERSION 104): the destination
+                         elements are IEEE half instead of bf16 (same fragment layout; the fp16-operand forward, MSST_FWD_HALF).
+                         Any other value: the job is skipped. */
     int32_t scale_rows; /* the first scale_rows SOURCE rows are multiplied by `scale` (0: none).  The round-3 attention backward   */
     float scale;        /* wants the q and k blocks of to_qkv^T pre-multiplied by dim_head^-0.5 (2^-3: exact in bf16).             */
 } MsstPrepJob;
 
+#define MSST_PREP_HALF 256
 /* Converts / transposes all matrices of the model into operand layout in ONE launch.
  * `jobs` is a DEVICE array. max_elems = max(rows*cols) over jobs.  job_bytes = sizeof(MsstPrepJob) of the CALLER's header: a
  * table laid out by another revision is refused (MSST_ERR_BADARG) instead of being read mis-strided.  err_flag (optional, one
@@ -98,6 +108,9 @@ typedef struct MsstBlockWeights {
     const void* wqkv32;  /* [3*H*64][96]  */
     const void* woutT32; /* [H*64][96]    */
     const void* wqkvT32; /* [96][3*H*64], pack = 1, scale_rows = 2*H*64, scale = dim_head^-0.5 (q and k blocks carry the softmax scale) */
+    /* MSST_VERSION 104, bf16 only, optional (null: MSST_FWD_HALF is refused): the four forward matrices as IEEE half, pack = 0 | MSST_PREP_HALF
+     * -- operands of the fp16-operand forward (same layout as wqkv / wout / w1 / w2) */
+    const void* wqkv_h; const void* wout_h; const void* w1_h; const void* w2_h;
 } MsstBlockWeights;
 
 /* a1+a2+a3+a5: BlockwisePatchEmbedding.to_patch/.embed (vit_spatial_spectral.py:197-222), position

@@ -32,7 +32,8 @@ class MsstPrepJob(Structure):
 class MsstBlockWeights(Structure):
     _fields_ = [("struct_bytes", ctypes.c_uint64)] + [(n, c_void_p) for n in (
         "wqkv", "wout", "w1", "w2", "wqkvT", "woutT", "w1T", "w2T",
-        "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2", "wqkv32", "woutT32", "wqkvT32")]
+        "ln1_g", "ln1_b", "bo", "ln2_g", "ln2_b", "b1", "b2", "wqkv32", "woutT32", "wqkvT32",
+        "wqkv_h", "wout_h", "w1_h", "w2_h")]
 
 
 class MsstBlockGrads(Structure):
@@ -45,6 +46,8 @@ BWD_DEFER_REDUCE = 512 << 8   # include/msst.h: MSST_BWD_DEFER_REDUCE
 X1_BF16 = 1024 << 8           # include/msst.h: MSST_X1_BF16
 SAVED_XN, SAVED_LSE, SAVED_RSTD = 1, 2, 4    # include/msst.h: MSST_SAVED_*
 LN1_FROM_XN = 2048 << 8       # include/msst.h: MSST_LN1_FROM_XN
+FWD_HALF = 4096 << 8          # include/msst.h: MSST_FWD_HALF
+PREP_HALF = 256               # include/msst.h: MSST_PREP_HALF
 _SIGS = {
     "msst_version": (c_int, []),
     "msst_last_error": (c_char_p, []),

@@ -26,11 +26,13 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
     const MsstPrepJob j = jobs[blockIdx.y];
     // malformed jobs are skipped (the job table lives in device memory: the host entry point cannot validate it) and reported
     // through the caller's error word: bit 0 = bad pack / shape, bit 1 = pack 1 on a shape that is not whole 32 x 16 fragments
-    if (j.pack < 0 || j.pack > 1 || j.rows < 1 || j.cols < 1) {
+    const bool half = sizeof(E) == 2 && (j.pack & MSST_PREP_HALF);   // destination elements IEEE half instead of bf16 (the fp16-operand forward)
+    if (j.pack < 0 || (j.pack & ~MSST_PREP_HALF) > 1 || (sizeof(E) != 2 && (j.pack & MSST_PREP_HALF)) || j.rows < 1 || j.cols < 1) {
         if (err_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err_flag, 1);
         return;
     }
-    if (sizeof(E) == 2 && j.pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) {
+    const int pack = j.pack & 1;
+    if (sizeof(E) == 2 && pack == 1 && (((j.transpose ? j.cols : j.rows) & 31) || ((j.transpose ? j.rows : j.cols) & 15))) {
         if (err_flag && blockIdx.x == 0 && threadIdx.x == 0) atomicOr(err_flag, 2);
         return;
     }
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
         // (see PBF16::ld_w; round 4: one 16-byte store instead of eight 2-byte ones, 55 -> see DESIGN us for the launch)
         const int R = j.transpose ? j.cols : j.rows, K = j.transpose ? j.rows : j.cols;   // logical [R][K] destination
         if ((K & 7) == 0) {
-            const int RB = j.pack ? 32 : 16, KB = j.pack ? 16 : 32;   // fragment = RB rows x KB k, lane = (k / 8) * RB + row
+            const int RB = pack ? 32 : 16, KB = pack ? 16 : 32;   // fragment = RB rows x KB k, lane = (k / 8) * RB + row
             if ((R % RB) == 0 && (K % KB) == 0) {
                 for (int i8 = blockIdx.x * 256 + threadIdx.x; i8 < n / 8; i8 += gridDim.x * 256) {
                     const int f = i8 / 64, lane = i8 - f * 64;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
                         const int src_i = j.transpose ? c * j.cols + r : r * j.cols + c;   // dst[r][c] = src[c][r] when transposed
                         float v = j.src[src_i];
                         if (src_i / j.cols < j.scale_rows) v *= j.scale;
-                        o[e] = (short)f2bf(v);
+                        o[e] = (short)(half ? f2h(v) : f2bf(v));
                     }
                     *reinterpret_cast<s16x8*>(dst + (long)i8 * 8) = o;
                 }
@@ -79,14 +81,14 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const MsstPrepJob* jo
             // fragment-packed destination (see PBF16::ld_w): logical (r, c) of the [R][K] destination matrix
             const int K = j.transpose ? j.rows : j.cols;
             const int r = i / K, c = i - r * K;
-            if (j.pack >= 1) {   // 32 rows x 16 k per fragment (v_mfma_f32_32x32x16_bf16 operand: lane = row % 32 + 32 (k % 16 / 8))
+            if (pack >= 1) {   // 32 rows x 16 k per fragment (v_mfma_f32_32x32x16_bf16 operand: lane = row % 32 + 32 (k % 16 / 8))
                 const int f = (r >> 5) * (K >> 4) + (c >> 4);
                 const int lane = ((c & 15) >> 3) * 32 + (r & 31);
-                dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+                dst[((long)f * 64 + lane) * 8 + (c & 7)] = half ? f2h(v) : f2bf(v);
             } else {
                 const int f = (r >> 4) * (K >> 5) + (c >> 5);
                 const int lane = ((c & 31) >> 3) * 16 + (r & 15);
-                dst[((long)f * 64 + lane) * 8 + (c & 7)] = f2bf(v);
+                dst[((long)f * 64 + lane) * 8 + (c & 7)] = half ? f2h(v) : f2bf(v);
             }
         }
     }
@@ -318,6 +320,14 @@ int msst_block_fwd(const MsstBlockWeights* w, const float* x, float* y, float* x
     a.x1_bf16 = (dbg & 1024) ? 1 : 0;
     if (a.x1_bf16 && !(prec == MSST_PREC_BF16 && heads == 8 && !(dbg & (16 | 64))))
         return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (MSST_X1_BF16 needs the role-split bf16 forward: 8 heads, no MSST_KERNEL_* flags)");
+    // MSST_FWD_HALF: fp16 operands -- the role-split forward only, and the caller must have prepared the half copies of its four matrices
+    a.half = (dbg & 4096) ? 1 : 0;
+    if (a.half) {
+        if (!(prec == MSST_PREC_BF16 && heads == 8 && !(dbg & (16 | 64))))
+            return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd (MSST_FWD_HALF needs the role-split bf16 forward: 8 heads, no MSST_KERNEL_* flags)");
+        if (!w->wqkv_h || !w->wout_h || !w->w1_h || !w->w2_h) return fail(MSST_ERR_BADARG, "msst_block_fwd (MSST_FWD_HALF without the half weight copies)");
+        a.w.wqkv = w->wqkv_h; a.w.wout = w->wout_h; a.w.w1 = w->w1_h; a.w.w2 = w->w2_h;
+    }
     a.drop = make_drop(dropout_p, seed, layer);
     a.xn_out = (xn_out && block_fwd_writes_xn(a, prec)) ? xn_out : nullptr;
     a.lse_out = (lse_out && block_fwd_writes_lse(a, prec)) ? lse_out : nullptr;
@@ -333,7 +343,12 @@ int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float
     const int dbg = (prec >> 8) & 0xffff;
     prec &= 0xff;
     // the role-split bf16 forward only: 8 heads, no kernel selection flags (MSST_X1_BF16 is the one flag it takes)
-    if (prec != MSST_PREC_BF16 || heads != 8 || (dbg & ~1024)) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (bf16, 8 heads, no MSST_KERNEL_* flags)");
+    if (prec != MSST_PREC_BF16 || heads != 8 || (dbg & ~(1024 | 4096))) return fail(MSST_ERR_UNSUPPORTED, "msst_block_fwd_stack (bf16, 8 heads, no MSST_KERNEL_* flags)");
+    const bool half = (dbg & 4096) != 0;
+    for (int j = 0; j < nblk; ++j) {
+        if (!bw_ok(w[j])) return fail(MSST_ERR_BADARG, "msst_block_fwd_stack (null block, or MsstBlockWeights of another header revision)");
+        if (half && (!w[j]->wqkv_h || !w[j]->wout_h || !w[j]->w1_h || !w[j]->w2_h)) return fail(MSST_ERR_BADARG, "msst_block_fwd_stack (MSST_FWD_HALF without the half weight copies)");
+    }
     StackArgs sa;
     BlockArgs& a = sa.base;
     memset(&a.w, 0, sizeof(a.w));
@@ -346,6 +361,7 @@ int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float
     a.dbg = 0;
     a.stamps = nullptr;
     a.x1_bf16 = (dbg & 1024) ? 1 : 0;
+    a.half = half ? 1 : 0;
     a.drop = make_drop(dropout_p, seed, layer0);
     if (lse_out && !block_fwd_writes_lse(a, prec)) lse_out = nullptr;   // same rule as msst_block_fwd: a statistics buffer past the 31-bit descriptor range is declined, not clipped
     sa.nblk = nblk;
@@ -353,7 +369,8 @@ int msst_block_fwd_stack(const MsstBlockWeights* const* w, int nblk, const float
     // index (maskedsst_amd lays its weight copies, parameters and activations out that way); anything else is refused
     auto blk_of = [&](int j, const float* xin) {
         StackBlk sb;
-        sb.wqkv = w[j]->wqkv; sb.wout = w[j]->wout; sb.w1 = w[j]->w1; sb.w2 = w[j]->w2;
+        sb.wqkv = half ? w[j]->wqkv_h : w[j]->wqkv; sb.wout = half ? w[j]->wout_h : w[j]->wout;
+        sb.w1 = half ? w[j]->w1_h : w[j]->w1; sb.w2 = half ? w[j]->w2_h : w[j]->w2;
         sb.ln1_g = w[j]->ln1_g; sb.ln1_b = w[j]->ln1_b; sb.bo = w[j]->bo; sb.ln2_g = w[j]->ln2_g; sb.ln2_b = w[j]->ln2_b; sb.b1 = w[j]->b1; sb.b2 = w[j]->b2;
         sb.x = xin; sb.y = y[j]; sb.x1 = x1 ? x1[j] : nullptr; sb.xn_out = xn_out ? xn_out[j] : nullptr; sb.lse_out = lse_out ? lse_out[j] : nullptr;
         sb.layer = layer0 + j; sb.pad_ = 0;

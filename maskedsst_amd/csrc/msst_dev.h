@@ -35,6 +35,15 @@ __device__ __forceinline__ s16x4 f2bf4(f32x4 c) {
     return __builtin_bit_cast(s16x4, __builtin_convertvector(c, hbf16x4));
 }
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// fp32 -> IEEE half, round-to-nearest-even (v_cvt_pk_f16_f32 on gfx950): the fp16-operand forward (MSST_FWD_HALF)
+typedef _Float16 hf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16_t f2h(float f) {
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ s16x4 f2h4(f32x4 c) {
+    return __builtin_bit_cast(s16x4, __builtin_convertvector(c, hf16x4));
+}
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

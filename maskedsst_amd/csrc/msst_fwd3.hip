@@ -114,8 +114,23 @@ __device__ __forceinline__ int sopaque3(int v) {
     return v;
 }
 
+// HALF (MSST_FWD_HALF, round 6): the GEMM operands of the forward are IEEE half instead of bf16 -- same 16-bit containers, same fragment
+// layouts, v_mfma_f32_16x16x32_f16 instead of ..._bf16 (same rate), v_cvt_pk_f16_f32 instead of v_cvt_pk_bf16_f32.  What is SAVED for the
+// backward (LN1 rows, centred x1 rows) stays bf16: the backward kernels are bf16.
+template <bool HALF>
+__device__ __forceinline__ s16x4 cv4(f32x4 c) {
+    if constexpr (HALF) return f2h4(c); else return f2bf4(c);
+}
+template <bool HALF>
+__device__ __forceinline__ f32x4 mma16(frag a, frag b, f32x4 c) {
+    if constexpr (HALF) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    } else return P::mma(a, b, c);
+}
+template <bool HALF>
 __device__ __forceinline__ frag pack2f(f32x4 lo, f32x4 hi) {
-    const s16x4 a = f2bf4(lo), b = f2bf4(hi);
+    const s16x4 a = cv4<HALF>(lo), b = cv4<HALF>(hi);
     frag r;
     r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
     r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
@@ -179,7 +194,7 @@ __device__ __forceinline__ void load_pair3(int pi, frag (&out)[2], const elem* w
 // 6.9 us per block saved, 4 % per step lost (block switches every group: MLP weights and small vectors reloaded, the weight ring
 // running into lines that left L2; 150 more scalar / LDS instructions per step in the R waves) -- ahead below ~14 tiles per
 // workgroup (batch 64, 5 / 6 tiles: -5.5 %; Houston shape: -7.3 %), behind above (batch 256 at the EnMAP shape, 20 / 22: +1.3 %): the host picks.
-template <bool DROP, bool STACK>
+template <bool DROP, bool STACK, bool HALF>
 __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::conditional<STACK, StackArgs, BlockArgs>::type args) {
     const BlockArgs& a = [&]() -> const BlockArgs& { if constexpr (STACK) return args.base; else return args; }();
     typedef Fwd3Smem SM;
@@ -416,8 +431,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    ca[t] = P::mma(ring[pi % NR][0], xf[t][ks], ca[t]);
-                                    cb[t] = P::mma(ring[pi % NR][1], xf[t][ks], cb[t]);
+                                    ca[t] = mma16<HALF>(ring[pi % NR][0], xf[t][ks], ca[t]);
+                                    cb[t] = mma16<HALF>(ring[pi % NR][1], xf[t][ks], cb[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 load_pair3(next_pair(pi), ring[pi % NR], pi + NR < 18 ? wqkv : wq_wrap, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                             }
 #pragma unroll
                             for (int t = 0; t < 4; ++t) {
-                                if (st < 2) qB[t][m] = pack2f(ca[t], cb[t]); else kA[t][m] = pack2f(ca[t], cb[t]);
+                                if (st < 2) qB[t][m] = pack2f<HALF>(ca[t], cb[t]); else kA[t][m] = pack2f<HALF>(ca[t], cb[t]);
                             }
                         } else {
                             const int mm = st - 4;
@@ -437,15 +452,15 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                                 const int pi = 3 * st + ks;
 #pragma unroll
                                 for (int t = 0; t < 4; ++t) {
-                                    cl[t] = P::mma(xf[t][ks], ring[pi % NR][0], cl[t]);
-                                    ch[t] = P::mma(xf[t][ks], ring[pi % NR][1], ch[t]);
+                                    cl[t] = mma16<HALF>(xf[t][ks], ring[pi % NR][0], cl[t]);
+                                    ch[t] = mma16<HALF>(xf[t][ks], ring[pi % NR][1], ch[t]);
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
                                 load_pair3(next_pair(pi), ring[pi % NR], pi + NR < 18 ? wqkv : wq_wrap, H, MSST_F3_WOFF ? 0 : sopaque3(pi + NR < 18 ? h : hn), voff, pi + NR < 18 ? hb_c : hb_n, HB, l16);
                                 __builtin_amdgcn_sched_barrier(0);
                             }
-                            vA[2 * mm][0] = pack2f(cl[0], cl[1]);     vA[2 * mm][1] = pack2f(cl[2], cl[3]);
-                            vA[2 * mm + 1][0] = pack2f(ch[0], ch[1]); vA[2 * mm + 1][1] = pack2f(ch[2], ch[3]);
+                            vA[2 * mm][0] = pack2f<HALF>(cl[0], cl[1]);     vA[2 * mm][1] = pack2f<HALF>(cl[2], cl[3]);
+                            vA[2 * mm + 1][0] = pack2f<HALF>(ch[0], ch[1]); vA[2 * mm + 1][1] = pack2f<HALF>(ch[2], ch[3]);
                         }
                     }
                 }
@@ -486,8 +501,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                         for (int t = 0; t < 4; ++t) {
                             if (!((NM[u] >> t) & 1u)) { s[u][t] = zero4(); continue; }
-                            s[u][t] = P::mma(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
-                            s[u][t] = P::mma(kA[t][1], qB[2 * jp + u][1], s[u][t]);
+                            s[u][t] = mma16<HALF>(kA[t][0], qB[2 * jp + u][0], zero4());   // C[i = key][j = query]
+                            s[u][t] = mma16<HALF>(kA[t][1], qB[2 * jp + u][1], s[u][t]);
                         }
                     {
                         // bit position of key 16 t + 4 g + r inside its 32-bit half of a 64-bit row mask: 16 (t & 1) + 4 g + r
@@ -564,12 +579,12 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        const frag p0 = pack2f(s[u][0], s[u][1]), p1 = pack2f(s[u][2], s[u][3]);
+                        const frag p0 = pack2f<HALF>(s[u][0], s[u][1]), p1 = pack2f<HALF>(s[u][2], s[u][3]);
 #pragma unroll
                         for (int dd = 0; dd < 4; ++dd) {
                             o[u][dd] = zero4();
-                            if (NM[u] & 3u) o[u][dd] = P::mma(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
-                            if (NM[u] & 12u) o[u][dd] = P::mma(vA[dd][1], p1, o[u][dd]);
+                            if (NM[u] & 3u) o[u][dd] = mma16<HALF>(vA[dd][0], p0, o[u][dd]);       // C[i = gathered channel][j = query]
+                            if (NM[u] & 12u) o[u][dd] = mma16<HALF>(vA[dd][1], p1, o[u][dd]);
                         }
                     }
                     // pack2(o[2u'], o[2u' + 1]) holds, in lane (c, g), the natural channels 32 u' + 8 g .. + 7 of query row 16 j + c
@@ -578,8 +593,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         elem* orow = &sm.ob[rd][(2 * jp + u) * 16 + (l4 & 15)][wv * 64 + 8 * (l4 >> 4)];
-                        *reinterpret_cast<frag*>(orow) = pack2f(o[u][0], o[u][1]);
-                        *reinterpret_cast<frag*>(orow + 32) = pack2f(o[u][2], o[u][3]);
+                        *reinterpret_cast<frag*>(orow) = pack2f<HALF>(o[u][0], o[u][1]);
+                        *reinterpret_cast<frag*>(orow + 32) = pack2f<HALF>(o[u][2], o[u][3]);
                     }
                     // q0 / q2 (middle of the round), q1 / q3 (its end: the round's O rows are complete)
                     F3_STAMP(2 + 5 * rd + 2 * jp);
@@ -659,8 +674,8 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             f32x4 n4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) n4[e] = (v[4*i+e] - mean) * rstd * lnp[f0 + e] + lnp[96 + f0 + e];
-            const s16x4 nb = f2bf4(n4);
-            *reinterpret_cast<s16x4*>(&sm.xn[k & 1][lr][f0]) = nb;
+            const s16x4 nb = f2bf4(n4);   // (the backward's rows are bf16 in either mode)
+            *reinterpret_cast<s16x4*>(&sm.xn[k & 1][lr][f0]) = HALF ? cv4<HALF>(n4) : nb;
             if (xn_out && tok >= 0) *reinterpret_cast<s16x4*>(xn_out + tok * 96 + f0) = nb;
         }
     };
@@ -709,7 +724,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int i = 0; i < 3; ++i) acc[jj][i] = P::mma(fw[s8][i], fo[s8 % 4][jj], acc[jj][i]);
+                    for (int i = 0; i < 3; ++i) acc[jj][i] = mma16<HALF>(fw[s8][i], fo[s8 % 4][jj], acc[jj][i]);
             });
     };
     // bias, dropout, residual -> x1 (registers + HBM); partial LN2 statistics of the 48 owned features -> ST
@@ -767,7 +782,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
                 f32x4 n4;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) n4[r] = (x1r[jj][i][r] - mean) * rstd * lnp[288 + m0 + r] + lnp[384 + m0 + r];
-                *reinterpret_cast<s16x4*>(&sm.xn2[32 * rh + 16 * jj + c3][m0]) = f2bf4(n4);
+                *reinterpret_cast<s16x4*>(&sm.xn2[32 * rh + 16 * jj + c3][m0]) = cv4<HALF>(n4);
             }
             mean_r[jj] = mean;
         }
@@ -819,7 +834,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) hh[jj][jn] = P::mma(w1f[jn][ks], xb[jj][ks], hh[jj][jn]);
+                for (int jn = 0; jn < 2; ++jn) hh[jj][jn] = mma16<HALF>(w1f[jn][ks], xb[jj][ks], hh[jj][jn]);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
@@ -829,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
                 for (int r = 0; r < 4; ++r) hh[jj][jn][r] = gelu_fast(hh[jj][jn][r] + lnp[576 + n0 + r]);
                 if (DROP && tok >= 0) hh[jj][jn] = drop4(drop_k, 3, (unsigned)(tok * 16 + (n0 >> 2)), hh[jj][jn]);
-                P::st_nat(&sm.hb[(2 * rh + jj) * 16][(2 * mh + jn) * 16], LDH, hh[jj][jn]);
+                *reinterpret_cast<s16x4*>(&sm.hb[(2 * rh + jj) * 16 + c3][(2 * mh + jn) * 16 + 4 * g3]) = cv4<HALF>(hh[jj][jn]);   // (P::st_nat's layout)
             }
         }
     };
@@ -858,7 +873,7 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int jm = 0; jm < 3; ++jm) yy[jj][jm] = P::mma(w2f[jm][ks], hbf[jj][ks], yy[jj][jm]);
+                for (int jm = 0; jm < 3; ++jm) yy[jj][jm] = mma16<HALF>(w2f[jm][ks], hbf[jj][ks], yy[jj][jm]);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj) {
             const long tok = tok_of(k, 32 * rh + 16 * jj + c3);
@@ -979,9 +994,11 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
 static int fwd3_attrs() {
     static std::atomic<bool> attr_set{false};
     if (attr_set) return 0;
-    const void* ks[4] = {reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, false>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, false>),
-                         reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, true>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, true>)};
-    for (int i = 0; i < 4; ++i) {
+    const void* ks[8] = {reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, false, false>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, false, false>),
+                         reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, true, false>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, true, false>),
+                         reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, false, true>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, false, true>),
+                         reinterpret_cast<const void*>(&block_fwd_rs_kernel<false, true, true>), reinterpret_cast<const void*>(&block_fwd_rs_kernel<true, true, true>)};
+    for (int i = 0; i < 8; ++i) {
         hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(Fwd3Smem));
         if (e != hipSuccess) return (int)e;
     }
@@ -1001,8 +1018,14 @@ int launch_block_fwd_rs_stack(const StackArgs& sa, int grid, hipStream_t st) {
     int rc = fwd3_attrs();
     if (rc) return rc;
     ProfScope ps(K_BLOCK_FWD, st);
-    if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, true>), dim3(grid), dim3(512), sizeof(Fwd3Smem), st, sa);
-    else hipLaunchKernelGGL((block_fwd_rs_kernel<false, true>), dim3(grid), dim3(512), sizeof(Fwd3Smem), st, sa);
+    const size_t smem = sizeof(Fwd3Smem);
+    if (a.half) {
+        if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, true, true>), dim3(grid), dim3(512), smem, st, sa);
+        else hipLaunchKernelGGL((block_fwd_rs_kernel<false, true, true>), dim3(grid), dim3(512), smem, st, sa);
+    } else {
+        if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, true, false>), dim3(grid), dim3(512), smem, st, sa);
+        else hipLaunchKernelGGL((block_fwd_rs_kernel<false, true, false>), dim3(grid), dim3(512), smem, st, sa);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1012,8 +1035,13 @@ int launch_block_fwd_rs(const BlockArgs& a, int grid, hipStream_t st) {
     int rc = fwd3_attrs();
     if (rc) return rc;
     ProfScope ps(K_BLOCK_FWD, st);
-    if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, false>), dim3(grid), dim3(512), smem, st, a);
-    else hipLaunchKernelGGL((block_fwd_rs_kernel<false, false>), dim3(grid), dim3(512), smem, st, a);
+    if (a.half) {
+        if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, false, true>), dim3(grid), dim3(512), smem, st, a);
+        else hipLaunchKernelGGL((block_fwd_rs_kernel<false, false, true>), dim3(grid), dim3(512), smem, st, a);
+    } else {
+        if (a.drop.thr) hipLaunchKernelGGL((block_fwd_rs_kernel<true, false, false>), dim3(grid), dim3(512), smem, st, a);
+        else hipLaunchKernelGGL((block_fwd_rs_kernel<false, false, false>), dim3(grid), dim3(512), smem, st, a);
+    }
     return (int)hipGetLastError();
 }
 

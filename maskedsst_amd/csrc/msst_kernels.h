@@ -33,6 +33,7 @@ struct BlockArgs {
     float* y;         // [tokens][96] block output
     float* x1;        // [tokens][96] mid-block residual (x + attn), saved for the backward; may be null
     int x1_bf16;      // MSST_X1_BF16: x1 holds bf16 (role-split forward only)
+    int half;         // MSST_FWD_HALF: the forward's GEMM operands are IEEE half (w.wqkv / wout / w1 / w2 then point at the half copies); role-split forward only
     void* xn_out;     // optional [tokens][96] bf16: LN1(x) exactly as the block used it, saved for the attention backward (head-per-wave kernel only)
     float* lse_out;   // optional [ntiles][H][64] fp32: per (tile, head, row) log2 of the softmax denominator of the scaled scores, max folded in
                       // (p = exp2(s scale log2 e - lse)): the attention backward then skips max / sum / 1 / x (role-split kernel only)

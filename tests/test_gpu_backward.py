@@ -432,9 +432,17 @@ def test_saved_softmax_statistics(cfg, drop, monkeypatch):
     # (1) block 0 (spatial): sequences = (b, c), 64 // N sequences per tile, rows in token order
     H, S, N = eng.enc.heads, eng.S, eng.N
     B = cfg["B"]
-    xn = o1["x1s"][0]._msst_xn.float().reshape(B * S, N, 96)
-    wq = params["encoder.spatial_spectral_transformer.1.layers.0.0.fn.to_qkv.weight"].cuda().to(torch.bfloat16).float()
-    qkv = (xn @ wq.t()).to(torch.bfloat16).float()
+    # operands as the forward rounded them: IEEE half (MSST_FWD_HALF, the default: LN1 rows straight from the fp32 statistics) or
+    # bf16 (the saved LN1 rows ARE its operands)
+    low = torch.float16 if eng.fwd_half else torch.bfloat16
+    if eng.fwd_half:
+        pre = "encoder.spatial_spectral_transformer.1.layers.0.0.norm."
+        xn = torch.nn.functional.layer_norm(o1["tok_masked"].float(), (96,), params[pre + "weight"].cuda(), params[pre + "bias"].cuda(), 1e-5)
+        xn = xn.to(low).float().reshape(B * S, N, 96)
+    else:
+        xn = o1["x1s"][0]._msst_xn.float().reshape(B * S, N, 96)
+    wq = params["encoder.spatial_spectral_transformer.1.layers.0.0.fn.to_qkv.weight"].cuda().to(low).float()
+    qkv = (xn @ wq.t()).to(low).float()
     q, k = qkv[..., :H * 64].reshape(B * S, N, H, 64), qkv[..., H * 64:2 * H * 64].reshape(B * S, N, H, 64)
     s = torch.einsum("bnhd,bmhd->bhnm", q, k) * (0.125 * 1.4426950408889634)
     ref = torch.logsumexp(s * 0.6931471805599453, dim=-1) * 1.4426950408889634      # log2 sum 2^s, [B S, H, N]

@@ -181,10 +181,14 @@ def test_depth12_bf16_vs_oracle(name):
             continue
         gerr[pname] = rel_l2(eng.fp.view(flat[id(p)], eng.fp.grad), gr)
     worst_name = max(gerr, key=gerr.get)
-    record("depth12_bf16", fixture=name, loss_err=loss_err, stage_err=stage_err, stage_l2=stage_l2, cos=cos,
+    record("depth12_bf16", fixture=name, fwd_half=bool(eng.fwd_half), loss_err=loss_err, stage_err=stage_err, stage_l2=stage_l2, cos=cos,
            dx0_err=dx0_err, worst_grad=gerr[worst_name], worst_grad_name=worst_name,
            median_grad=float(np.median(list(gerr.values()))))
     assert loss_err < bars["loss"], loss_err
+    if eng.fwd_half and name in L12:
+        # round 6: with IEEE-half GEMM operands in the forward (MSST_FWD_HALF, the default) the timed kernels meet north_star's loss
+        # tolerance against the REFERENCE's anchors on all three depth-12 fixtures (bf16 operands: 0.8e-4 / 2.6e-4 / 2.3e-4)
+        assert loss_err < 1e-4, loss_err
     assert max(stage_err.values()) < bars["stage"], stage_err
     assert cos > bars["cos"], cos
     assert dx0_err < bars["dx0"], dx0_err
@@ -313,6 +317,36 @@ def test_peaky_x8_conditioning(name):
     assert all(torch.isfinite(out[k]).all() for k in STAGES)
     assert max(stage_err.values()) < 0.4, stage_err
     assert finite and bf16_loss_err < 5e-2, bf16_loss_err
+
+
+@pytest.mark.parametrize("name", ["simmim_50b_L12_B8.npz", "simmim_200b_L12_B4.npz"])
+def test_half_vs_bf16_operand_forward(name, monkeypatch):
+    """MSST_FWD_HALF (round 6): the role-split forward with IEEE-half GEMM operands against the same kernel with bf16 operands
+    (MSST_FWD_HALF=0), both against the oracle and the reference's loss anchor.  tools/bf16_error_table.py predicts it on the CPU: the
+    bf16 forward's loss error is systematic and owned by the rounding of the weights (-2.7e-4 / +0.8e-4 on these fixtures); with half
+    operands 7e-6.  Required: half meets 1e-4 on the anchor and is closer to the oracle at every stage."""
+    g = load_golden(name)
+    cfg = g["cfg"]
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    masks = model.draw_masks(cfg["B"])
+    from oracle import simmim_forward
+    with torch.no_grad():
+        ref = simmim_forward(params, x, oracle_cfg_from(cfg), masks=masks)
+    eng = model.engine()
+    lf = float(g["loss"])
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MSST_FWD_HALF", flag)
+        out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+        torch.cuda.synchronize()
+        assert eng.fwd_half == (flag == "1")
+        res[flag] = dict(loss_err=abs(out["loss"].item() - lf) / lf, **{k: rel_l2(out[k], ref[k]) for k in ("after_spatial", "enc_out", "pred")})
+    monkeypatch.delenv("MSST_FWD_HALF")
+    record("half_vs_bf16_operand_forward", fixture=name, half=res["1"], bf16=res["0"])
+    assert res["1"]["loss_err"] < 1e-4, res
+    assert res["0"]["loss_err"] < 9e-4, res
+    for k in ("after_spatial", "enc_out", "pred"):
+        assert res["1"][k] < res["0"][k], (k, res)
 
 
 def test_full_size_b256_bf16():
