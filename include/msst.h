@@ -49,6 +49,10 @@ extern "C" {
                                             backward.  Why: the bf16 forward's loss error against the fp32 reference (2.6e-4 on the Houston-shape anchor) is
                                             systematic and owned by the rounding of the WEIGHTS (tools/bf16_error_table.py); with half operands it is 7e-6.  Every
                                             operand of the forward is a LayerNorm row, a weight, a probability or a bounded activation: inside half's range */
+#define MSST_LSE_RENORM (8192 << 8)       /* msst_block_bwd / _chain (MSST_VERSION 104): lse_saved comes from a forward whose scores are not the backward's own -- the
+                                            half-operand forward (MSST_FWD_HALF) against the bf16 recomputation here.  The two-head attention backward then uses lse
+                                            as the exponent offset only and normalises every row by its own sum (p = softmax of ITS scores exactly, one reduction
+                                            more); without the flag p = exp2(s c - lse) as saved.  Always pass it for blocks run with MSST_FWD_HALF */
 #define MSST_LN1_FROM_XN (2048 << 8)      /* msst_block_bwd_chain (MSST_VERSION 104): the fused LN1 + MLP launch takes xhat of LN1 from the saved bf16 LN1 rows and
                                             the saved rstd -- xhat = (xn_saved - ln1_b) / ln1_g, rstd = the tail of lse_saved (MSST_SAVED_RSTD) -- instead of
                                             re-reading and re-normalising the fp32 block input x: 192 bytes per token less of 2304.  The caller sets it only when

@@ -47,6 +47,7 @@ X1_BF16 = 1024 << 8           # include/msst.h: MSST_X1_BF16
 SAVED_XN, SAVED_LSE, SAVED_RSTD = 1, 2, 4    # include/msst.h: MSST_SAVED_*
 LN1_FROM_XN = 2048 << 8       # include/msst.h: MSST_LN1_FROM_XN
 FWD_HALF = 4096 << 8          # include/msst.h: MSST_FWD_HALF
+LSE_RENORM = 8192 << 8        # include/msst.h: MSST_LSE_RENORM
 PREP_HALF = 256               # include/msst.h: MSST_PREP_HALF
 _SIGS = {
     "msst_version": (c_int, []),

@@ -578,6 +578,7 @@ static int block_bwd_impl(const MsstBlockWeights* w, const MsstBlockGrads* g, co
         aa.H = heads; aa.ntok = ntok; aa.scale = 0.125f; aa.drop = drop;
         aa.queue = (tile_queue && heads / 2 <= 32) ? tile_queue : nullptr;
         aa.lse = fast_rows ? lse_saved : nullptr;   // (only the two-head kernel reads it; launch_block_bwd_attn drops it for the others)
+        aa.lse_renorm = (dbg & 8192) ? 1 : 0;       // MSST_LSE_RENORM: statistics of a half-operand forward
         aa.dbg = dbg & ~8;
         aa.stamps = nullptr;
 #ifdef MSST_STAMPS

@@ -157,7 +157,11 @@ __device__ __forceinline__ s16x8 ident32_frag(int f, int i, int hi) {
 // LSE: the forward saved log2 of every query's softmax denominator (BlockArgs.lse_out): the softmax phase computes p = exp2(s c - lse)
 // directly -- no row maximum, no row sum, no reciprocal, one cross-lane reduction (delta) instead of three.  The 64 values of a
 // (tile, head) ride in with the tile's rows: one 256-byte LDS-DMA per head into a buffer of the tile's parity.
-template <bool DROP, bool QUEUE, bool LSE>
+// LSE = 2 (MSST_LSE_RENORM, round 6): the forward that saved the statistics multiplied IEEE-half operands (MSST_FWD_HALF), so its scores
+// are not the ones recomputed here from bf16 rows and weights -- on peaky rows (|s c| ~ 40) the difference is several percent of a
+// probability.  lse then only serves as the exponent offset (no row maximum needed: the exponentials stay near 1) and the row is
+// normalised by its OWN sum: p = softmax of this kernel's scores exactly, as without saved statistics, for one reduction more than LSE = 1.
+template <bool DROP, bool QUEUE, int LSE>
 __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     lds_char* const sm = (lds_char*)smem_raw;
@@ -543,6 +547,14 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                             } else pr[t][r] = e;
                         }
                     }
+                    if (LSE == 2) {
+                        f32x4 es = zero4();
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (on(t)) es = es + pr[t];
+                        const float inv = __builtin_amdgcn_rcpf(colgroup_sum((es[0] + es[1]) + (es[2] + es[3])));
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) if (on(t)) pr[t] = pr[t] * inv;
+                    }
                 } else {
                 float mx = -INFINITY;
 #pragma unroll
@@ -860,20 +872,22 @@ int launch_block_bwd_attn_r4(const AttnBwdArgs& a, int nchunk, hipStream_t st) {
     if (!a.xn || !a.dab || !a.w.wqkv32 || !a.w.woutT32 || !a.w.wqkvT32 || nchunk < 1 || nchunk > a.ntiles) return MSST_ERR_BADARG;
     if (a.ntok * 192 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit row offsets of the copy-out descriptor
     typedef void (*kern_t)(AttnBwdArgs);
-    const kern_t kerns[8] = {&block_bwd_attn_r4_kernel<false, false, false>, &block_bwd_attn_r4_kernel<true, false, false>,
-                             &block_bwd_attn_r4_kernel<false, true, false>, &block_bwd_attn_r4_kernel<true, true, false>,
-                             &block_bwd_attn_r4_kernel<false, false, true>, &block_bwd_attn_r4_kernel<true, false, true>,
-                             &block_bwd_attn_r4_kernel<false, true, true>, &block_bwd_attn_r4_kernel<true, true, true>};
+    const kern_t kerns[12] = {&block_bwd_attn_r4_kernel<false, false, 0>, &block_bwd_attn_r4_kernel<true, false, 0>,
+                              &block_bwd_attn_r4_kernel<false, true, 0>, &block_bwd_attn_r4_kernel<true, true, 0>,
+                              &block_bwd_attn_r4_kernel<false, false, 1>, &block_bwd_attn_r4_kernel<true, false, 1>,
+                              &block_bwd_attn_r4_kernel<false, true, 1>, &block_bwd_attn_r4_kernel<true, true, 1>,
+                              &block_bwd_attn_r4_kernel<false, false, 2>, &block_bwd_attn_r4_kernel<true, false, 2>,
+                              &block_bwd_attn_r4_kernel<false, true, 2>, &block_bwd_attn_r4_kernel<true, true, 2>};
     if (a.lse && (long)a.ntiles * a.H * 256 >= 0x7ffffff0L) return MSST_ERR_UNSUPPORTED;   // 32-bit offsets of the statistics' descriptor
     if (!attr_set) {
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 12; ++i) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kerns[i]), hipFuncAttributeMaxDynamicSharedMemorySize, R4_SMEM);
             if (e != hipSuccess) return (int)e;
         }
         attr_set = true;
     }
     ProfScope ps(K_BWD_ATTN, st);
-    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.queue ? 2 : 0) + (a.lse ? 4 : 0)], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
+    hipLaunchKernelGGL(kerns[(a.drop.thr ? 1 : 0) + (a.queue ? 2 : 0) + (a.lse ? (a.lse_renorm ? 8 : 4) : 0)], dim3(nchunk, a.H / 2), dim3(512), R4_SMEM, st, a);
     return (int)hipGetLastError();
 }
 

@@ -125,6 +125,7 @@ struct AttnBwdArgs {
     Drop drop;
     int* queue;       // optional (two-head kernel): one zeroed counter per head pair -> dynamic tile queue instead of the static partition
     const float* lse; // optional (two-head kernel): [ntiles][H][64] saved by the forward (BlockArgs.lse_out)
+    int lse_renorm;   // MSST_LSE_RENORM: the forward's scores are not this kernel's (half-operand forward): exp2(s c - lse) rows are renormalised by their own sum
 };
 
 struct Ln1BwdArgs {

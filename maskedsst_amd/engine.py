@@ -378,6 +378,7 @@ class Engine:
             x1._msst_xn = xn if (wrote.value & _lib.SAVED_XN) else None
             x1._msst_lse = lse if (wrote.value & _lib.SAVED_LSE) else None
             x1._msst_rstd = bool(wrote.value & _lib.SAVED_RSTD) and x1._msst_lse is not None   # rstd of LN1 rides in the tail of the statistics buffer
+            x1._msst_half = bool(self.fwd_half)   # the statistics are those of half-operand scores: the backward renormalises (MSST_LSE_RENORM)
         acts.append(y)
         x1s.append(x1)
 
@@ -418,6 +419,7 @@ class Engine:
                 x1[j]._msst_xn = xn[j] if (wrote.value & _lib.SAVED_XN) else None
                 x1[j]._msst_lse = lse[j] if (lse is not None and (wrote.value & _lib.SAVED_LSE)) else None
                 x1[j]._msst_rstd = bool(wrote.value & _lib.SAVED_RSTD) and x1[j]._msst_lse is not None
+                x1[j]._msst_half = bool(self.fwd_half)
                 x1s.append(x1[j])
             else:
                 x1s.append(None)
@@ -557,7 +559,8 @@ class Engine:
                     ctypes.byref(self._bw[i - 1]) if prev else null_w, ctypes.byref(self._bg[i - 1]) if prev else null_g,
                     _p(acts[i]), _p(x1s[i]), _p(x1s[i - 1]) if prev else _p(None), _p(dy) if i == last else _p(None),
                     _p(None) if prev else _p(dx0), _p(dx1), _p(part), _p(slab_i), self.grid_rows, self.attn_chunks, mode,
-                    B, S, N, H, self.prec | x1flag | xnflag | (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab),
+                    B, S, N, H, self.prec | x1flag | xnflag | (_lib.LSE_RENORM if getattr(x1s[i], "_msst_half", False) else 0) |
+                    (_lib.BWD_DEFER_REDUCE if defer else 0), drop[0], drop[1], i, _p(xns[i]), _p(lses[i]), _p(dab),
                     1 if i == last else 0, _p(queue), _stream()),
                     "msst_block_bwd_chain")
                 if not defer:
@@ -607,7 +610,7 @@ class Engine:
         _lib.check(self.lib.msst_block_bwd(
             ctypes.byref(self._bw[i]), ctypes.byref(self._bg[i]), _p(x), _p(x1), _p(dy), _p(dx),
             _p(dx1), _p(part), _p(slab), self.grid_rows, self.attn_chunks, mode, B, S, N, H,
-            self.prec | _kernel_flags() | x1flag,
+            self.prec | _kernel_flags() | x1flag | (_lib.LSE_RENORM if getattr(x1, "_msst_half", False) else 0),
             drop[0], drop[1], i, _p(getattr(x1, "_msst_xn", None)), _p(getattr(x1, "_msst_lse", None)), _p(dab), _stream()), "msst_block_bwd")
         return dx
 

@@ -236,7 +236,7 @@ def test_stack_launch_refuses_operands_that_are_not_a_constant_stride_apart():
 
     def call(slots, nblk=n, w=wv):
         ys = VP(*[buf[s].data_ptr() for s in slots])
-        return eng.lib.msst_block_fwd_stack(w, nblk, _p(x0), ys, None, None, None, MODE_SPATIAL, B, S, N, H, eng.prec, 0, 0.0, 0, 0, None, _stream())
+        return eng.lib.msst_block_fwd_stack(w, nblk, _p(x0), ys, None, None, None, MODE_SPATIAL, B, S, N, H, eng.prec | eng._half_flag(0), 0, 0.0, 0, 0, None, _stream())
 
     assert call([0, 1, 2]) == 0          # contiguous slices
     assert call([0, 2, 4]) == 0          # any constant stride
