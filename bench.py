@@ -86,6 +86,8 @@ def main():
                     help="backward persistent grids draw their tiles from a queue (what attach_data_parallel selects) instead of the static partition")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the live HBM-traffic measurement (two short rocprofv3 --pmc child runs of this script: FETCH_SIZE, WRITE_SIZE)")
+    ap.add_argument("--no-alt", action="store_true",
+                    help="skip the extra timed region with bf16 GEMM operands in the forward (MSST_FWD_HALF=0)")
     ap.add_argument("--no-probe", action="store_true",
                     help="skip the box probe (msst_debug_box_probe: ~0.1 s before the warmup and after the timed region)")
     ap.add_argument("--force-dp", action="store_true",
@@ -233,6 +235,35 @@ def main():
     final_loss = float(loss.item())
     probe_after = box_probe() if not args.no_probe else None
 
+    # the same K steps with the forward's GEMM operands in bf16 (MSST_FWD_HALF=0: round 5's forward; the engine reads the switch per
+    # launch) -- what the IEEE-half operands of the default cost, measured in this run, reported next to `value`
+    alt = None
+    if args.precision == "bf16" and not args.no_alt and os.environ.get("MSST_FWD_HALF", "1") != "0":
+        os.environ["MSST_FWD_HALF"] = "0"
+        try:
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            a0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            ael = time.perf_counter() - a0
+        finally:
+            del os.environ["MSST_FWD_HALF"]
+        if world > 1:
+            t = torch.tensor([ael], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ael = float(t.item())
+        alt = {"forward_gemm_operands": "bf16 (MSST_FWD_HALF=0)", "value": round(B * world * args.steps / ael, 2), "unit": "samples/s",
+               "ms_per_step": round(1e3 * ael / args.steps, 3),
+               "what": "the same steps with bf16 instead of IEEE-half GEMM operands in the forward (loss error against the reference anchors "
+                       "0.8e-4 / 2.6e-4 instead of 7e-6 / 2e-6: parity_note); not the headline"}
+
     # second timed region: the same step fed by the input pipeline (SyntheticCubeLoader: worker thread, pinned staging,
     # asynchronous host->device copies) instead of one resident batch -- reported next to `value`
     pipe = None
@@ -275,6 +306,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "forward_gemm_operands": ("fp16 (IEEE half, MSST_FWD_HALF; backward bf16)" if getattr(model.engine(), "fwd_half", False) else args.precision),
             "config": {"workload": f"SimMIM pretrain step (fwd+bwd+AdamW), EnMAP-shape cubes 8x8x{args.bands}, "
                                    f"depth {args.depth}x2, dim 96, heads {args.heads}, mlp 64, mask 0.7/4/tube, dropout {args.dropout}",
                        "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}"},
@@ -293,6 +325,8 @@ def main():
                                "tile_queue": bool(model.engine().tile_queue)}
         if pipe is not None:
             out["pipeline_inclusive"] = pipe
+        if alt is not None:
+            out["bf16_operand_forward"] = alt
         if kernels:
             # dominant kernel among the MFMA kernels; algorithmic FLOPs per launch = tokens * per-token FLOPs
             # (half the launches are spatial blocks, Lseq = N; half spectral, Lseq = S -> use the mean)
@@ -455,7 +489,7 @@ def measure_traffic(args):
     import tempfile
     child = ["--steps", "1", "--warmup", "1", "--batch", str(args.batch), "--bands", str(args.bands), "--depth", str(args.depth),
              "--heads", str(args.heads), "--precision", args.precision, "--dropout", str(args.dropout),
-             "--no-cpu-baseline", "--no-profile", "--no-pipeline", "--no-traffic", "--no-probe"] + (["--tile-queue"] if args.tile_queue else [])
+             "--no-cpu-baseline", "--no-profile", "--no-pipeline", "--no-traffic", "--no-probe", "--no-alt"] + (["--tile-queue"] if args.tile_queue else [])
     out = tempfile.mkdtemp(prefix="msst_pmc_", dir="/tmp")
     t0 = time.perf_counter()
     try:

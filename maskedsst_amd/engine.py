@@ -228,44 +228,82 @@ class Engine:
         if self.prec == PREC_BF16:
             self._ln1_guard_launch()
 
-    # ------------------------------------------------------------------ guard of MSST_LN1_FROM_XN
+    # ------------------------------------------------------------------ parameter guards of MSST_LN1_FROM_XN and MSST_FWD_HALF
     LN1_XN_MAX_RATIO = 12.0   # max |ln1_b / ln1_g|: xhat = (row - b) / g amplifies the bf16 rounding of the saved rows by 1 + |b / g| / |xhat|
+    HALF_MAX_BOUND = 3.0e4    # bound on |q|, |k|, |v|, |attention output| and the MLP's hidden pre-activation (half's largest finite value: 65504)
 
     def _ln1_guard_launch(self):
-        """max |ln1_b / ln1_g| over every block (inf when a gamma is 0), computed on the device from the flat parameter buffer and
-        copied to pinned host memory WITHOUT a synchronisation: read a step later (LN parameters move by <= lr per step)."""
-        if getattr(self, "_ln1_idx", None) is None or self._ln1_idx_key is not self._jobs:
-            names = [f"{s}.{l}.ln1_{k}" for k in ("g", "b") for s, l in self._layers()]
-            offs = np.array([self.fp.segments[n][0] for n in names], dtype=np.int64)
-            idx = (offs[:, None] + np.arange(96)[None, :]).reshape(2, -1)
-            self._ln1_idx = torch.from_numpy(idx).to(self.fp.flat.device)
+        """Two numbers over every block, computed on the device from the flat parameter buffer (a [blocks, floats per block] view: the
+        blocks' parameters lie a constant stride apart) and copied to pinned host memory WITHOUT a synchronisation -- read some steps later
+        (parameters move by <= lr per step; both thresholds are orders of magnitude, not margins):
+          * max |ln1_b / ln1_g| (inf when a gamma is 0): MSST_LN1_FROM_XN divides by gamma;
+          * a bound on every half operand the forward produces (MSST_FWD_HALF): |W x| <= max_row ||W_row||_1 * max |x|, with
+            |LayerNorm row| <= max |gamma| * sqrt(96) + max |beta| -- q / k / v (and the attention output, a convex combination of v
+            rows) from Wqkv and LN1, the hidden pre-activation (>= |GELU output|) from W1, b1 and LN2."""
+        if getattr(self, "_ln1_idx_key", None) is not self._jobs:
+            layers = self._layers()
+            names = ["ln1_g", "ln1_b", "wqkv", "ln2_g", "ln2_b", "w1", "b1"]
+            seg = self.fp.segments
+            base = [seg[f"{layers[0][0]}.{layers[0][1]}.{n}"][0] for n in names]
+            starts = [min(seg[f"{s_}.{l}.{n}"][0] for n in names) for s_, l in layers]
+            lo = min(starts)
+            stride = None
+            order = sorted(range(len(layers)), key=lambda i: starts[i])
+            affine = True
+            for a_, b_ in zip(order, order[1:]):
+                d = starts[b_] - starts[a_]
+                stride = d if stride is None else stride
+                affine = affine and d == stride
+            rel = [o - starts[0] for o in base]
+            for i, (s_, l) in enumerate(layers):
+                affine = affine and all(seg[f"{s_}.{l}.{n}"][0] - starts[i] == r for n, r in zip(names, rel))
+            span = max(seg[f"{layers[0][0]}.{layers[0][1]}.{n}"][0] + seg[f"{layers[0][0]}.{layers[0][1]}.{n}"][1] for n in names) - starts[0]
+            self._guard_view = (lo, stride if len(layers) > 1 else span, len(layers), dict(zip(names, rel)), span) if affine and (stride or 0) >= span else None
             self._ln1_idx_key = self._jobs
-            self._ln1_host = torch.empty(1, dtype=torch.float32, pin_memory=True)
+            self._ln1_host = torch.empty(2, dtype=torch.float32, pin_memory=True)
             self._ln1_ev = None
             self._ln1_ratio = None
+            self._half_bound = None
             self._ln1_calls = 0
+        if self._guard_view is None:
+            return                                                     # (not our own flat layout: both switches stay off)
         self._ln1_calls += 1
-        if self._ln1_ev is not None and self._ln1_ev.query():      # the copy launched some parameter updates ago has landed: adopt its value
-            self._ln1_ratio = float(self._ln1_host[0])
+        if self._ln1_ev is not None and self._ln1_ev.query():      # the copy launched some parameter updates ago has landed: adopt its values
+            self._ln1_ratio, self._half_bound = float(self._ln1_host[0]), float(self._ln1_host[1])
             self._ln1_ev = None
-        # a fresh value every 8th parameter update is enough (the threshold is an order of magnitude, not a margin; LN parameters
-        # move by <= lr per step); the very first call synchronises once
+        # fresh values every 8th parameter update are enough; the very first call synchronises once
         if self._ln1_ratio is not None and (self._ln1_ev is not None or self._ln1_calls % 8 != 1):
             return
-        g = self.fp.flat[self._ln1_idx[0]]
-        b = self.fp.flat[self._ln1_idx[1]]
-        ratio = (b.abs() / g.abs()).nan_to_num(nan=float("inf")).max().reshape(1)
-        self._ln1_host.copy_(ratio, non_blocking=True)
+        lo, stride, n, rel, span = self._guard_view
+        H = self.enc.heads
+        m = torch.as_strided(self.fp.flat, (n, span), (stride, 1), lo)
+
+        def t(name, *shape):
+            k = int(np.prod(shape))
+            return m[:, rel[name]:rel[name] + k].reshape((n,) + shape)
+        g1, b1_, g2, b2_ = t("ln1_g", 96).abs(), t("ln1_b", 96).abs(), t("ln2_g", 96).abs(), t("ln2_b", 96).abs()
+        ratio = (b1_ / g1).nan_to_num(nan=float("inf")).max()
+        ln1_max = g1.amax(1) * (96 ** 0.5) + b1_.amax(1)
+        ln2_max = g2.amax(1) * (96 ** 0.5) + b2_.amax(1)
+        qkv = t("wqkv", 3 * H * DH, 96).abs().sum(-1).amax(1) * ln1_max
+        hid = t("w1", MLP, 96).abs().sum(-1).amax(1) * ln2_max + t("b1", MLP).abs().amax(1)
+        bound = torch.maximum(qkv, hid).nan_to_num(nan=float("inf")).max()
+        self._ln1_host.copy_(torch.stack((ratio, bound)), non_blocking=True)
         self._ln1_ev = torch.cuda.Event()
         self._ln1_ev.record()
         if self._ln1_ratio is None:
             self._ln1_ev.synchronize()
-            self._ln1_ratio = float(self._ln1_host[0])
+            self._ln1_ratio, self._half_bound = float(self._ln1_host[0]), float(self._ln1_host[1])
             self._ln1_ev = None
 
     def ln1_xn_ok(self):
         r = getattr(self, "_ln1_ratio", None)
         return r is not None and r <= self.LN1_XN_MAX_RATIO
+
+    def half_ok(self):
+        """may the forward's GEMM operands be IEEE half?  (every one of them provably below HALF_MAX_BOUND; unknown -> no)"""
+        b = getattr(self, "_half_bound", None)
+        return b is not None and b <= self.HALF_MAX_BOUND
 
     # ------------------------------------------------------------------ forward pieces
     def tokenize(self, img, mask_u8=None, with_pos=True, emb_drop=(0.0, 0)):
@@ -350,7 +388,8 @@ class Engine:
 
     def _half_flag(self, flags):
         """MSST_FWD_HALF for a forward launch: the role-split kernel (bf16 mode, 8 heads, no kernel selection flags), unless MSST_FWD_HALF=0"""
-        self.fwd_half = (self.prec == PREC_BF16 and self.enc.heads == 8 and flags == 0 and os.environ.get("MSST_FWD_HALF", "1") != "0")
+        self.fwd_half = (self.prec == PREC_BF16 and self.enc.heads == 8 and flags == 0 and os.environ.get("MSST_FWD_HALF", "1") != "0"
+                         and self.half_ok())
         return _lib.FWD_HALF if self.fwd_half else 0
 
     def _fwd_block(self, acts, x1s, i, save, drop, x1_bf16, want_lse, flags):

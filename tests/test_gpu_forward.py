@@ -156,6 +156,32 @@ def test_softmax_scale_sensitivity_on_peaky_rows(prec, monkeypatch):
     assert smallest is not None and smallest <= (2.0 ** -5 if prec == "bf16" else 2.0 ** -9), (smallest, errs)
 
 
+def test_half_operand_guard():
+    """MSST_FWD_HALF is used only while every half operand of the forward is provably in range (engine.half_ok: max_row ||W_row||_1 x
+    the largest possible LayerNorm row, below 3e4 of half's 65504): a model whose MLP could overflow falls back to bf16 operands by
+    itself and still matches the oracle at the bf16 bars."""
+    from oracle import simmim_forward
+    cfg = dict(bands=50, depth=2, B=4)
+    model, params, x = build_product(cfg, precision="bf16", device="cuda")
+    name = "encoder.spatial_spectral_transformer.3.layers.1.1.fn.net.0.bias"
+    with torch.no_grad():
+        dict(model.named_parameters())[name].fill_(4.0e4)
+        params[name].fill_(4.0e4)
+    masks = model.draw_masks(cfg["B"])
+    eng = model.engine()
+    out = eng.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    torch.cuda.synchronize()
+    assert not eng.half_ok() and not eng.fwd_half
+    with torch.no_grad():
+        ref = simmim_forward(params, x, oracle_cfg_from(cfg), masks=masks)
+    assert torch.isfinite(out["enc_out"]).all()
+    assert relerr(out["enc_out"], ref["enc_out"]) < 9e-3
+    model2, _, _ = build_product(cfg, precision="bf16", device="cuda")
+    eng2 = model2.engine()
+    eng2.simmim_forward_stages(x.cuda(), masks[0], masks[1])
+    assert eng2.half_ok() and eng2.fwd_half and eng2._half_bound < 200.0     # a freshly initialised model: ~50
+
+
 STACK_CASES = [
     dict(bands=200, depth=2, B=5),                                          # 100 / 320 tiles: one tile per workgroup (a lone group, padded with idle steps) or two
     dict(bands=50, depth=12, B=8),                                          # BASELINE config 2's depth: twelve blocks per launch

@@ -4,7 +4,7 @@
 for rnd in 1 2; do
   for lib in "$@"; do
     echo "== [$lib] round $rnd"
-    python3 tools/with_lib.py $lib bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pipeline --no-traffic --profile-all ${AB_ARGS:-} 2>/dev/null | tail -1 | python3 -c "
+    python3 tools/with_lib.py $lib bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-pipeline --no-traffic --no-alt --profile-all ${AB_ARGS:-} 2>/dev/null | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], {k: round(v['avg_us'],1) for k,v in d['kernels'].items() if k.startswith('block') or k.startswith('reduce')})"
   done

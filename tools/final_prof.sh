@@ -15,7 +15,7 @@ python3 -m pytest tests -m gpu -q --no-header 2>&1 | tail -3 > $OUT/gpu_tests.tx
 unset MSST_STRICT_PARITY
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/peak_microbench.hip -o /tmp/peak_microbench && /tmp/peak_microbench > $OUT/peak_microbench.json
 export TMPDIR=/tmp
-B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic"
+B="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic --no-alt --no-probe"
 for pass in "FETCH_SIZE" "WRITE_SIZE"; do
   rocprofv3 --pmc $pass --kernel-trace -f csv -d $OUT/pmc_$pass -- $B > /dev/null 2>&1 || true
 done
@@ -33,7 +33,7 @@ rocprofv3 --kernel-trace --stats -f csv -d $OUT/stats -o "$TAG" -- python3 bench
 find $OUT/stats -name "*kernel_trace.csv" -delete
 timeout 900 python3 bench.py > $OUT/bench_default.json 2>$OUT/bench_default.err || true
 tail -1 $OUT/bench_default.json | cut -c1-600
-timeout 600 python3 bench.py --no-cpu-baseline --no-traffic --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
+timeout 600 python3 bench.py --no-cpu-baseline --no-traffic --no-alt --profile-all > $OUT/bench_profile_all.json 2>/dev/null || true
 # other configurations (parity-test shapes and the batch sweep), one line each
 ( python3 bench.py --no-cpu-baseline --no-traffic --dropout 0 | tail -1
   python3 bench.py --no-cpu-baseline --no-traffic --bands 50 | tail -1
@@ -44,19 +44,19 @@ cut -c1-200 $OUT/bench_other_configs.jsonl
 # CU contention: the step with N occupancy-probe workgroups held on a side stream, default grid and the DP grid
 # static partition (single-GPU default), static partition on grids sized for 32 free CUs (round 3's DP choice; with and without a
 # probe), and the dynamic tile queue (round 4's DP choice: no reservation)
-( python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile | tail -1
-  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n | tail -1; done
-  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief 1 --thief-us 1 --thief-reserve 32 | tail -1
-  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n --thief-reserve 32 | tail -1; done
-  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --tile-queue | tail -1
-  for n in 8 16 32 48; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --cu-thief $n --tile-queue | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
+( python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt --cu-thief $n | tail -1; done
+  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt --cu-thief 1 --thief-us 1 --thief-reserve 32 | tail -1
+  for n in 8 16 32; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt --cu-thief $n --thief-reserve 32 | tail -1; done
+  python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt --tile-queue | tail -1
+  for n in 8 16 32 48; do python3 bench.py --no-cpu-baseline --no-traffic --no-pipeline --no-profile --no-alt --cu-thief $n --tile-queue | tail -1; done ) > $OUT/cu_contention.jsonl 2>/dev/null || true
 python3 - << 'PY'
 import json
 for l in open("gpurun_out/final/cu_contention.jsonl"):
     d = json.loads(l); print(d.get("cu_thief"), d["ms_per_step"], d["value"])
 PY
 # data-parallel wiring on one GPU: a one-rank RCCL group, bucket hooks fired by the real backward (bench.py --force-dp)
-rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic > $OUT/dp_bench.txt 2>&1 || true
+rocprofv3 --kernel-trace -f csv -d $OUT/dp -- python3 bench.py --force-dp --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-pipeline --no-traffic --no-alt > $OUT/dp_bench.txt 2>&1 || true
 python3 tools/dp_overlap.py $OUT/dp > $OUT/dp_overlap.txt 2>&1 || true; cat $OUT/dp_overlap.txt
 find $OUT/dp -name "*.csv" -size +512k -delete
 hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gate_microbench.hip -o /tmp/gate_microbench && timeout 120 /tmp/gate_microbench > $OUT/gate_microbench.jsonl || true

@@ -47,8 +47,11 @@ __device__ __forceinline__ void gap(int g, float (&f)[8], unsigned (&u)[8], doub
     for (int k = 0; k < NS; ++k) asm volatile("s_mov_b32 s22, 0x1234" ::: "s22");   // (an SALU issue slot that leaves SCC alone: the loop's own compare / branch live around these)
 }
 
-template <int NV, int NL, int NS, bool PK>
-__global__ __launch_bounds__(256, 1) void gate_kernel(float* out, int pairs, unsigned long long* clk) {
+// W2 (round 6): the SHIPPED structure instead -- two waves per SIMD (512 threads), each carrying ONE head's stream of
+// a tile (98 MFMAs + its fillers), every chain independent as above: what the scalar-class diet (2 -> 1 scalar instruction per MFMA)
+// can buy a kernel that already overlaps two instruction streams per SIMD.
+template <int NV, int NL, int NS, bool PK, bool W2 = false>
+__global__ __launch_bounds__(W2 ? 512 : 256, 1) void gate_kernel(float* out, int pairs, unsigned long long* clk) {
     __shared__ double lds[2048];
     float f[8]; unsigned u[8]; double pd[4]; f32x16 acc[8]; f32x16 r[2]; double w[2];
     bf16x8 ma, mb;
@@ -57,7 +60,7 @@ __global__ __launch_bounds__(256, 1) void gate_kernel(float* out, int pairs, uns
     for (int i = 0; i < 4; ++i) { float2 t = {1.0f + 1e-6f * i, 1.0f - 1e-6f * i}; pd[i] = __builtin_bit_cast(double, t); }
     double pc; { float2 t = {1.0000001f, 0.9999999f}; pc = __builtin_bit_cast(double, t); }
     w[0] = 1.0; w[1] = 2.0;
-    for (int i = threadIdx.x; i < 2048; i += 256) lds[i] = i;
+    for (int i = threadIdx.x; i < 2048; i += (W2 ? 512 : 256)) lds[i] = i;
     float fa = 0.37f + threadIdx.x * 1e-3f, fb = 1.0001f; unsigned ub = 0x9E3779B1u;
     unsigned la = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds + (threadIdx.x & 63) * 16;
     asm volatile("s_mov_b64 s[20:21], 0x5555" ::: "s20", "s21");
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256, 1) void gate_kernel(float* out, int pairs, uns
     for (int it = 0; it < pairs; ++it) {
         // one tile pair = 196 MFMAs: 24 groups of 8 (eight independent accumulators) + 4
 #pragma unroll 1
-        for (int grp = 0; grp < 24; ++grp) {
+        for (int grp = 0; grp < (W2 ? 12 : 24); ++grp) {
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(ma), "v"(mb));   // (opaque: as a builtin the compiler deletes the MFMAs of the mixed streams)
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, 1) void gate_kernel(float* out, int pairs, uns
             }
         }
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < (W2 ? 2 : 4); ++g) {
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc[g]) : "v"(ma), "v"(mb));   // (opaque: as a builtin the compiler deletes the MFMAs of the mixed streams)
             gap<NV, NL, NS, PK>(g, f, u, pd, fa, fb, ub, pc, la, r, w);
         }
@@ -86,22 +89,22 @@ __global__ __launch_bounds__(256, 1) void gate_kernel(float* out, int pairs, uns
     float s = 0.f;
     for (int i = 0; i < 8; ++i) s += f[i] + (float)u[i] + acc[i][3] + (i < 4 ? (float)pd[i] : 0.f);
     s += r[0][0] + r[1][0];
-    out[blockIdx.x * 256 + threadIdx.x] = s;
+    out[blockIdx.x * 256 + (threadIdx.x & 255)] = s;
 }
 
-template <int NV, int NL, int NS, bool PK>
+template <int NV, int NL, int NS, bool PK, bool W2 = false>
 static int run(const char* what, float* out, unsigned long long* clk) {
     const int pairs = 40;
     unsigned long long h = 0;
     for (int rep = 0; rep < 3; ++rep) {
-        hipLaunchKernelGGL((gate_kernel<NV, NL, NS, PK>), dim3(256), dim3(256), 0, 0, out, pairs, clk);
+        hipLaunchKernelGGL((gate_kernel<NV, NL, NS, PK, W2>), dim3(256), dim3(W2 ? 512 : 256), 0, 0, out, pairs, clk);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(&h, clk, 8, hipMemcpyDeviceToHost));
     }
     const double cyc = (double)h / pairs;
-    printf("{\"mix\": \"%s\", \"per_mfma\": {\"valu\": %d, \"lds\": %d, \"salu\": %d}, \"packed_f32\": %s, \"per_tile_pair\": {\"mfma\": 196, \"valu\": %d, \"lds\": %d, \"salu\": %d}, "
+    printf("{\"waves_per_simd\": %d, \"mix\": \"%s\", \"per_mfma\": {\"valu\": %d, \"lds\": %d, \"salu\": %d}, \"packed_f32\": %s, \"per_tile_pair\": {\"mfma\": 196, \"valu\": %d, \"lds\": %d, \"salu\": %d}, "
            "\"cycles_per_tile_pair\": %.0f, \"cycles_per_mfma\": %.1f, \"vs_shipped_13100\": %.3f}\n",
-           what, NV, NL, NS, PK ? "true" : "false", 196 * NV, 196 * NL, 196 * NS, cyc, cyc / 196.0, cyc / 13100.0);
+           W2 ? 2 : 1, what, NV, NL, NS, PK ? "true" : "false", 196 * NV, 196 * NL, 196 * NS, cyc, cyc / 196.0, cyc / 13100.0);
     fflush(stdout);
     return 0;
 }
@@ -118,5 +121,13 @@ int main() {
     run<6, 2, 1, true>("today's mix with packed f32 in it", out, clk);
     run<6, 2, 2, false>("today's mix + the compiler's SALU (s_waitcnt / s_nop / branches: ~2 per gap)", out, clk);
     run<8, 2, 2, false>("8 VALU per gap", out, clk);
+    // round 6: two waves per SIMD, one head's stream each (the shipped structure, stall free) -- today's mix by the round-5 census (4.8 VALU /
+    // 1.7 LDS / 2.1 scalar-class per MFMA) and the verdict's target (one scalar-class instruction per MFMA)
+    run<0, 0, 0, false, true>("two waves: bare MFMAs", out, clk);
+    run<5, 2, 2, false, true>("two waves: today's mix (5 VALU + 2 LDS + 2 scalar per MFMA)", out, clk);
+    run<5, 2, 1, false, true>("two waves: target mix (5 VALU + 2 LDS + 1 scalar per MFMA)", out, clk);
+    run<5, 2, 0, false, true>("two waves: no scalar instruction at all", out, clk);
+    run<4, 2, 1, false, true>("two waves: 4 VALU + 2 LDS + 1 scalar", out, clk);
+    run<4, 1, 1, false, true>("two waves: 4 VALU + 1 LDS + 1 scalar", out, clk);
     return 0;
 }

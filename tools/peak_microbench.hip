@@ -66,6 +66,34 @@ __global__ __launch_bounds__(256) void mfma_peak(float* out, int iters, unsigned
     }
 }
 
+// the same loop on v_mfma_f32_16x16x32_f16 (round 6: the forward's operands are IEEE half): does the wider multiplier cost clock under the power cap?
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+template <int MODE>
+__global__ __launch_bounds__(256) void mfma_peak_f16(float* out, int iters, unsigned long long* clk) {
+    f16x8 a, b;
+    for (int i = 0; i < 8; ++i) {
+        const unsigned id = (blockIdx.x * 256 + threadIdx.x) * 16 + i;
+        a[i] = (_Float16)(MODE == 0 ? 0.f : mb_rand(id));
+        b[i] = (_Float16)(MODE == 0 ? 0.f : mb_rand(id + 8));
+    }
+    const unsigned long long t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    f32x4 c0 = {}, c1 = {}, c2 = {}, c3 = {}, c4 = {}, c5 = {}, c6 = {}, c7 = {};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c7, 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) s += c0[i] + c1[i] + c2[i] + c3[i] + c4[i] + c5[i] + c6[i] + c7[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_readcyclecounter() - t0; clk[1] = wall_clock64() - w0; }
+}
+
 // ------------------------------------------------------------------ HBM copy
 __global__ __launch_bounds__(256) void copy4(const f32x4* __restrict__ src, f32x4* __restrict__ dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
@@ -279,6 +307,12 @@ int main() {
         printf("  \"mfma_bf16_32x32x16_by_operands\": {\"zero\": %.1f, \"constant\": %.1f, \"smooth_pattern\": %.1f, \"random\": %.1f},\n", tf32[0], tf32[1], tf32[2], tf32[3]);
         printf("  \"mfma_shader_clock_mhz_by_operands\": {\"zero\": %.0f, \"constant\": %.0f, \"smooth_pattern\": %.0f, \"random\": %.0f},\n", mhz[0], mhz[1], mhz[2], mhz[3]);
         printf("  \"mfma_bf16_16x16x32_by_operands\": {\"zero\": %.1f, \"random\": %.1f},\n", tf16[0], tf16[3]);
+        {
+            double th[2], mh[2], tb = 0, mbz = 0;
+            if (run(mfma_peak_f16<0>, f16, th[0], &mh[0]) || run(mfma_peak_f16<3>, f16, th[1], &mh[1]) || run(mfma_peak<16, 3>, f16, tb, &mbz)) return 1;
+            printf("  \"mfma_f16_16x16x32_by_operands\": {\"zero\": %.1f, \"random\": %.1f}, \"mfma_f16_16x16x32_clock_mhz\": {\"zero\": %.0f, \"random\": %.0f}, "
+                   "\"mfma_bf16_16x16x32_random_again\": {\"tflops\": %.1f, \"clock_mhz\": %.0f},\n", th[0], th[1], mh[0], mh[1], tb, mbz);
+        }
         CK(hipFree(d_clk));
     }
     // HBM copy: 1 GiB read + 1 GiB written
