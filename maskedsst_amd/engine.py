@@ -276,7 +276,8 @@ class Engine:
             return
         lo, stride, n, rel, span = self._guard_view
         H = self.enc.heads
-        m = torch.as_strided(self.fp.flat, (n, span), (stride, 1), lo)
+        base = self.fp.flat[lo:]
+        m = base.as_strided((n, span), (stride, 1), base.storage_offset())
 
         def t(name, *shape):
             k = int(np.prod(shape))

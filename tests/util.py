@@ -91,7 +91,9 @@ def _identity(row):
 
 # comparisons of two summation orders of the SAME arithmetic: their size is decided by whether a last-bit difference flips a bf16
 # rounding somewhere (1e-7 for one input, 1e-4 for the next): not a measurement a ratio can be held against
-STRICT_EXEMPT = {"chained_backward_matches_unchained"}
+STRICT_EXEMPT = {"chained_backward_matches_unchained", "attn_bwd_kernels_agree"}
+# ... and the variant-vs-variant halves of tests that ALSO record errors against the oracle (those stay in the tier)
+STRICT_EXEMPT_KEYS = {"saved_softmax_statistics": {"dx", "worst_grad", "lse_abs_err"}, "ln1_backward_from_saved_rows": {"dx", "worst_grad"}}
 
 
 def strict_violations(test, kv, factor=STRICT_FACTOR, floor=1e-6, unmatched=None):
@@ -121,7 +123,7 @@ def strict_violations(test, kv, factor=STRICT_FACTOR, floor=1e-6, unmatched=None
                 bad.append((key, got, ref))
 
     for k, v in kv.items():
-        if k not in base:
+        if k not in base or k in STRICT_EXEMPT_KEYS.get(test, ()):
             continue
         if k == "cos" and isinstance(v, float):
             cmp("1-cos", 1.0 - v, 1.0 - base[k])
