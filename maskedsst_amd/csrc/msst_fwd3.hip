@@ -105,7 +105,7 @@ constexpr int BT_WQKV = 0, BT_W1 = 2, BT_LN1G = 4, BT_X = 11;   // blktab column
 // what a walk step works on (STACK: the step's block of the run; else the launch's one block)
 struct StepBlk {
     const elem* wqkv; const elem* wout;
-    const float* x; float* y; float* x1; elem* xn_out; float* lse_out;
+    const float* x; float* y; float* x1; elem* xn_out;   // (the statistics buffer: sm.blktab / a.lse_out where it is used)
     int layer;
 };
 
@@ -284,11 +284,10 @@ __global__ __launch_bounds__(512, 2) void block_fwd_rs_kernel(typename std::cond
             q.y = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[j][BT_X + 1]));
             q.x1 = reinterpret_cast<float*>(const_cast<char*>(sm.blktab[j][BT_X + 2]));
             q.xn_out = reinterpret_cast<elem*>(const_cast<char*>(sm.blktab[j][BT_X + 3]));
-            q.lse_out = b0.lse_out ? reinterpret_cast<float*>(const_cast<char*>(at_blk(b0.lse_out, st.lse_out, j))) : nullptr;
             q.layer = b0.layer + j;
         } else {
             q.wqkv = reinterpret_cast<const elem*>(a.w.wqkv); q.wout = reinterpret_cast<const elem*>(a.w.wout);
-            q.x = a.x; q.y = a.y; q.x1 = a.x1; q.xn_out = reinterpret_cast<elem*>(a.xn_out); q.lse_out = a.lse_out; q.layer = a.drop.layer;
+            q.x = a.x; q.y = a.y; q.x1 = a.x1; q.xn_out = reinterpret_cast<elem*>(a.xn_out); q.layer = a.drop.layer;
         }
         return q;
     };
