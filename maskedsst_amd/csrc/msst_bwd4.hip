@@ -548,6 +548,7 @@ __global__ __launch_bounds__(512, 1) void block_bwd_attn_r4_kernel(AttnBwdArgs a
                         }
                     }
                     if (LSE == 2) {
+                        // (the row sums on the matrix cores instead -- ones x bf16(e), no cross-lane VALU -- measured 531 against 519 us: LABNOTES round 6, row 16)
                         f32x4 es = zero4();
 #pragma unroll
                         for (int t = 0; t < 4; ++t) if (on(t)) es = es + pr[t];
