@@ -29,6 +29,7 @@ from conftest import load_golden, oracle_cfg_from, seed_all
 POINTS = ["ln1_rows", "wqkv", "qkv", "p", "o", "wout", "ln2_rows", "w1", "gelu_out", "w2"]
 
 
+SPLIT = False
 LOW = torch.bfloat16   # --dtype f16: the same ten points rounded to IEEE half instead (11 significant bits; the forward's operands are
                        # LayerNorm rows, weights, probabilities and bounded activations: all inside half's range)
 
@@ -45,8 +46,11 @@ def make_block(on):
         h = r("ln1_rows", om.layer_norm(x, params[pre + "0.norm.weight"], params[pre + "0.norm.bias"]))
         wqkv, wo, bo = params[pre + "0.fn.to_qkv.weight"], params[pre + "0.fn.to_out.0.weight"], params[pre + "0.fn.to_out.0.bias"]
         Bq, n, _ = h.shape
-        qkv = r("qkv", h @ r("wqkv", wqkv).t())
         inner = wqkv.shape[0] // 3
+        wr = r("wqkv", wqkv)
+        if "wqk" in on or "wv" in on:      # (--split: the q | k rows and the v rows of to_qkv.weight rounded separately)
+            wr = torch.cat((bf(wqkv[:2 * inner]) if "wqk" in on else wqkv[:2 * inner], bf(wqkv[2 * inner:]) if "wv" in on else wqkv[2 * inner:]))
+        qkv = r("qkv", h @ wr.t())
         dh = inner // heads
         q, k, v = (t.reshape(Bq, n, heads, dh).transpose(1, 2) for t in qkv.split(inner, dim=-1))
         attn = r("p", torch.softmax((q @ k.transpose(-1, -2)) * (dh ** -0.5), dim=-1))
@@ -73,6 +77,9 @@ def losses(name, draws):
     out = {}
     variants = [("fp32", set())] + [("all_bf16", set(POINTS))] + [("fp32:" + p, set(POINTS) - {p}) for p in POINTS] + \
                [("only:" + p, {p}) for p in POINTS]
+    if SPLIT:
+        variants = [("fp32", set()), ("only:wq+wk", {"wqk"}), ("only:wv", {"wv"}),
+                    ("all but wv (the QK path and every other point rounded, Wv exact)", (set(POINTS) - {"wqkv"}) | {"wqk"})]
     state = (np.random.get_state(), torch.get_rng_state())
     for tag, on in variants:
         om.block = make_block(on)
@@ -93,8 +100,10 @@ def main():
     ap.add_argument("--draws", type=int, default=6)
     ap.add_argument("--json", default="")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--split", action="store_true", help="only: to_qkv.weight's q | k rows against its v rows")
     a = ap.parse_args()
-    global LOW
+    global LOW, SPLIT
+    SPLIT = a.split
     LOW = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     torch.set_num_threads(8)
     rows = []
