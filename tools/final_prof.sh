@@ -6,7 +6,7 @@ set -eu
 TAG="${1:?usage: final_prof.sh rNN}"
 cd "${GRAFT_REPO_ROOT:?not on a gpurun box}"
 OUT=gpurun_out/final
-rm -rf "$OUT"; mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"   # (on the box; the build container's own gpurun_out/final keeps files of earlier rounds that this pass does not write: make_profiles.py only takes files newer than the pass's bench_default.json minus an hour)
 export MSST_ROUND="$TAG" MSST_RECORD=1 MSST_STRICT_PARITY=1   # strict tier: every recorded error within 1.5x the committed baseline (tests/util.py)
 # parity measurements of the round (tests/util.py::record appends to gpurun_out/parity_$TAG.jsonl)
 rm -f "gpurun_out/parity_$TAG.jsonl"

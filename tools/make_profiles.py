@@ -51,6 +51,8 @@ for n, dst in (("dp_overlap.txt", f"{tag}_dp_overlap.txt"), ("parity_measured.js
                ("gpu_tests.txt", f"{tag}_gpu_tests.txt"), ("peak_microbench.json", f"{tag}_peak_microbench.json"),
                ("cu_contention.jsonl", f"{tag}_dp_cu_contention.jsonl"), ("gate_microbench.jsonl", f"{tag}_gate_microbench.jsonl"),
                ("fwd_stack_ab.txt", f"{tag}_fwd_stack_ab.txt"), ("gate_qkv.txt", f"{tag}_gate_qkv.txt")):
-    if os.path.exists(os.path.join(SRC, n)):
+    # (gpurun MERGES the box's files into gpurun_out/: a file this pass did not write may be a leftover of an earlier round -- skip it)
+    fresh = os.path.getmtime(os.path.join(SRC, "bench_default.json")) - 3600
+    if os.path.exists(os.path.join(SRC, n)) and os.path.getmtime(os.path.join(SRC, n)) >= fresh:
         shutil.copy(os.path.join(SRC, n), os.path.join(DST, dst))
 print(json.dumps(kern, indent=1))
