@@ -21,6 +21,16 @@ CASES = [
 ]
 
 
+# round 6: peaky attention rows (to_qkv.weight x4: logit std ~5, row maxima 0.5-0.8) through the kernels the 8-head fixtures do not
+# reach -- the 4-wave forward, the one-head (odd head count) and two-head (2 / 4 heads) attention backward, the fp32 templates
+PEAKY_SMALL = [
+    dict(bands=20, depth=1, B=3, heads=4, qkv_scale=4),
+    dict(bands=30, depth=1, B=3, heads=2, tube_masking=False, qkv_scale=4),
+    dict(bands=20, depth=1, B=2, heads=3, qkv_scale=4),
+    dict(bands=50, depth=2, B=4, qkv_scale=4),
+]
+
+
 def grads_pair(cfg, prec):
     from oracle import simmim_forward
     model, params, x = build_product(cfg, precision=prec, device="cuda")
@@ -54,7 +64,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+@pytest.mark.parametrize("cfg", CASES + PEAKY_SMALL, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_param_grads_fp32(cfg):
     """fp32 MFMA mode: every gradient element within 2e-4 of the oracle (relative to the tensor max)."""
     tol = 2e-4
@@ -74,7 +84,7 @@ def test_param_grads_fp32(cfg):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
+@pytest.mark.parametrize("cfg", CASES + PEAKY_SMALL, ids=lambda c: "-".join(f"{k}{v}" for k, v in c.items()))
 def test_param_grads_bf16(cfg):
     """bf16 MFMA mode.  The L1 loss gradient is sign(pred - target): bf16 rounding of the forward
     flips the sign of the few entries with pred ~= target, so element-wise comparison of the
@@ -83,7 +93,9 @@ def test_param_grads_bf16(cfg):
     oracle.  Bars: the BF16_* constants above (<= 2x measured)."""
     model, params, ref, loss = grads_pair(cfg, "bf16")
     lr = ref["loss"].item()
-    assert abs(loss.item() - lr) <= BF16_LOSS * abs(lr)
+    # peaky rows: 3-4x the bf16 noise of the uniform-attention cases per block (tests/test_gpu_depth12.py: 1.3e-2 / 1.45e-2 per block)
+    pk = 4.0 if "qkv_scale" in cfg else 1.0
+    assert abs(loss.item() - lr) <= pk * BF16_LOSS * abs(lr)
     ga, gb = [], []
     for name, p in model.named_parameters():
         if params[name].grad is not None:
@@ -91,7 +103,7 @@ def test_param_grads_bf16(cfg):
             gb.append(params[name].grad.double().reshape(-1))
     ga, gb = torch.cat(ga), torch.cat(gb)
     cos = float((ga * gb).sum() / (ga.norm() * gb.norm()))
-    assert cos > BF16_COS, cos
+    assert cos > 1.0 - pk * pk * (1.0 - BF16_COS), cos
     # (2) same sign pattern as the oracle
     from maskedsst_amd.masking import inverse_csr
     eng = model.engine()
@@ -115,8 +127,8 @@ def test_param_grads_bf16(cfg):
     worst = max(errs, key=errs.get)
     record("param_grads_bf16", cfg=cfg, loss_err=abs(loss.item() - lr) / abs(lr), cos=cos, dx0_err=dx0_err,
            worst_grad=errs[worst], worst_grad_name=worst)
-    assert dx0_err < BF16_DX0, dx0_err
-    bad = [(n, e) for n, e in errs.items() if not e < BF16_GRAD]
+    assert dx0_err < (10.0 if pk > 1 else 1.0) * BF16_DX0, dx0_err    # (peaky: measured 1.8e-2 ... 2.5e-2 through the two blocks: 1.3e-2 per block)
+    bad = [(n, e) for n, e in errs.items() if not e < pk * BF16_GRAD]
     assert not bad, bad
 
 
